@@ -1,0 +1,195 @@
+/*
+ * pram_hip.h — C ABI of libpram_hip.so, the MI355X (gfx950) kernels underneath the PRAM
+ * per-query hot path (SFD2 extract -> SegNetViT recognise -> GML/AdaGML match + Sinkhorn).
+ *
+ * The reference (feixue94/pram) is pure Python on stock torch ops and has no FFI; the boundary
+ * it exposes is dict-in/dict-out nn.Modules.  This header is the native
+ * boundary a maintainer binds underneath those modules (ctypes stub in INTEGRATION.md); each
+ * entry names the reference torch-op site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; fp32 unless typed otherwise.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs.
+ *   - no allocation inside; workspaces are passed in and sized by the *_workspace_bytes query.
+ *   - return 0 on success, negative on error (PRAM_E_*); pram_last_error() gives the text.
+ *   - ragged batches: `*_lens` are per-batch-element int32 device arrays (NULL = every
+ *     element has the padded max length).  The reference has no masks; a padded row/key is
+ *     never read into a softmax, so each element computes exactly its B=1 result.
+ *   - token matrices are row-major [rows][ld]; heads are 64-wide column blocks.
+ */
+#ifndef PRAM_HIP_H
+#define PRAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRAM_OK 0
+#define PRAM_E_ARG (-1)      /* bad shape / alignment / null pointer */
+#define PRAM_E_LAUNCH (-2)   /* hipLaunchKernel failed */
+#define PRAM_E_UNSUPPORTED (-3)
+
+int pram_hip_version(void);
+const char* pram_last_error(void);
+
+/* ---------------------------------------------------------------- token linear algebra */
+
+/* flags for pram_linear_f32 */
+#define PRAM_LIN_ROTARY 1  /* rotate column pairs (c, c+32) of each 64-wide head for c < rot_cols */
+
+/* out[m][n] = alpha * ( [A0 | A1] · Wᵀ + bias ) + residual          (nn.Linear sites:
+ * nets/segnetvit.py:87-95,157-164; nets/gml.py:118-126,151-159,220,235; K6 in SURVEY.md §2.1)
+ *   A0 [m][lda0] supplies k in [0,k0), A1 [m][lda1] supplies k in [k0,k0+k1) (the torch.cat of
+ *   segnetvit.py:106); a1 may be NULL with k1 = 0.  W is [n][k0+k1] (torch layout).
+ *   PRAM_LIN_ROTARY: W rows were pre-permuted so that within each 64-wide head the even
+ *   rotary dims are columns 0..31 and the odd dims 32..63; cos/sin are [m][32]
+ *   (apply_cached_rotary_emb, segnetvit.py:21-23).
+ * Constraints: k0 % 32 == 0 when k1 > 0; (k0+k1) % 4 == 0; lda % 4 == 0. */
+int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                    const float* w, const float* bias, const float* residual, int ldr,
+                    float* out, int ldo, int m, int n, float alpha, int flags,
+                    const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
+
+/* Batched C_b = alpha * A_b · B_bᵀ (einsum 'bmd,bnd->bmn', nets/gml.py:282; K12).
+ * A_b = a + b*stride_a, [m_max][lda]; B_b [n_max][ldb]; C_b [m_max][ldc]. */
+int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
+                      long long stride_b, float* c, int ldc, long long stride_c, int batch,
+                      int m_max, int n_max, int k, float alpha, void* stream);
+
+/* y = GELU(LayerNorm(x)) rowwise, eps 1e-5, exact erf GELU (nn.LayerNorm + nn.GELU,
+ * nets/segnetvit.py:92-93,161-162; K11).  In place when y == x.  cols <= 1024, cols % 4 == 0 */
+int pram_layernorm_gelu_f32(const float* x, int ldx, float* y, int ldy, const float* gamma,
+                            const float* beta, int rows, int cols, float eps, void* stream);
+
+/* Fourier positional encoding (normalize_keypoints nets/utils.py:17-24 +
+ * LearnableFourierPositionalEncoding nets/segnetvit.py:35-40; K7):
+ *   nk = (kpts - (cx,cy)) / scale ; proj = Wr·nk ; cos_out/sin_out [rows][32].
+ * Pass cx = cy = 0, scale = 1 for pre-normalised keypoints. */
+int pram_fourier_encoding_f32(const float* kpts, const float* wr, float cx, float cy, float scale,
+                              float* cos_out, float* sin_out, int rows, void* stream);
+
+/* ---------------------------------------------------------------- attention (graded kernel) */
+
+/* Flash-style multi-head attention, head_dim 64, exact-fp32 MFMA (Attention.forward
+ * nets/segnetvit.py:73-76; cross attention nets/gml.py:175-179 is two calls; K8/K9):
+ *   out[b, i, h*64:(h+1)*64] = softmax_j( scale * q[b,i,h]·k[b,j,h] ) · v[b,j,h]
+ * q rows of batch b start at row b*m_max (k/v: b*n_max).  lse2 (optional) receives
+ * log2-domain log-sum-exp [batch][heads][m_max] for pram_attention_colmean_f32. */
+int pram_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                       float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens,
+                       int batch, int heads, int m_max, int n_max, float scale, void* stream);
+
+/* Column means of the attention matrix (AdaGML Attention.forward nets/adagml.py:148,229; K10):
+ *   colmean[b][j] = 1/(heads*m_b) * sum_h sum_i softmax(scale q k^T)[b,h,i,j] */
+int pram_attention_colmean_f32(const float* q, int ldq, const float* k, int ldk, const float* lse2,
+                               float* colmean, const int* q_lens, const int* k_lens, int batch,
+                               int heads, int m_max, int n_max, float scale, void* stream);
+
+/* ---------------------------------------------------------------- optimal transport + matches */
+
+size_t pram_sinkhorn_workspace_bytes(int batch, int m_max, int n_max);
+
+/* sink_algorithm (nets/gml.py:27-46; K13): plain-domain Sinkhorn on the dustbin-augmented
+ * (m+1)x(n+1) matrix, `iters` iterations, eps 1e-8.  dist [batch][m_max][ldd].
+ * bin_score: device pointer to the scalar parameter.  Outputs:
+ *   p_out (optional) [batch][m_max+1][ldp] the final P*u*v (for parity with sink_algorithm)
+ *   compute_matches (nets/gml.py:304-319; K14) fused into the last pass:
+ *   matches0 [batch][m_max] int64 (-1 none), matches1 [batch][n_max], mscores0/1 fp32.
+ * Rows >= m_b / cols >= n_b of the outputs are filled with -1 / 0. */
+int pram_sinkhorn_match_f32(const float* dist, int ldd, const int* m_lens, const int* n_lens,
+                            const float* bin_score, int iters, float match_threshold,
+                            float* p_out, int ldp, long long* matches0, long long* matches1,
+                            float* mscores0, float* mscores1, int batch, int m_max, int n_max,
+                            void* workspace, void* stream);
+
+/* dual_softmax (nets/gml.py:20-24; K15) + compute_matches; same outputs as above. */
+int pram_dual_softmax_match_f32(const float* dist, int ldd, const int* m_lens, const int* n_lens,
+                                const float* bin_score, float match_threshold, float* p_out, int ldp,
+                                long long* matches0, long long* matches1, float* mscores0,
+                                float* mscores1, int batch, int m_max, int n_max, void* workspace,
+                                void* stream);
+
+/* ---------------------------------------------------------------- AdaGML token pruning (K10) */
+
+/* PoolingLayer tail + pruning bookkeeping (nets/adagml.py:137,354-372,516-531), one token set per
+ * workgroup: conf = sigmoid(logit); n_below[s] = #(conf < thr) over the set's current tokens (the
+ * check_if_stop numerator).  If lens_in[s] >= n_min_tokens the tokens with conf > thr are compacted,
+ * order preserved, into x_out / cos_out / sin_out / ind_out (else all are copied); lens_out[s] = kept.
+ * x [sets][t_max][ldx], cos/sin [sets][t_max][32], ind [sets][t_max] (original token ids).
+ * Out-of-place only.  conf_out (optional) [sets][t_max] receives the confidences. */
+int pram_adagml_prune_f32(const float* conf_logit, float thr, int n_min_tokens, const int* lens_in,
+                          const float* x_in, const float* cos_in, const float* sin_in, const int* ind_in,
+                          float* x_out, float* cos_out, float* sin_out, int* ind_out, int* lens_out,
+                          int* n_below, float* conf_out, int sets, int t_max, int ldx, void* stream);
+
+/* Scatter the matches of the pruned sets back to full size (nets/adagml.py:382-396):
+ * out_matches[b][ind0[i]] = ind1[matches0[i]] where matches0[i] >= 0; out_scores[b][ind0[i]] = mscores0[i].
+ * out_* [batch][m_full] must be pre-filled with -1 / 0. */
+int pram_adagml_scatter_f32(const long long* matches0, const float* mscores0, const int* ind0, const int* ind1,
+                            const int* lens0, int batch, int t_max, int m_full, long long* out_matches,
+                            float* out_scores, void* stream);
+
+/* ---------------------------------------------------------------- SFD2 (NHWC feature maps) */
+
+/* Implicit-GEMM convolution, NHWC, exact-fp32 MFMA (ResNet4x conv stack nets/sfd2.py:281-293,
+ * 331-333; K1):  out = act( (conv(in, w) + bias) * scale + shift + residual )
+ *   in [b][h][w][cin]; w [cout][ks][ks][cin] (repacked OIHW); out [b][ho][wo][cout],
+ *   ho = (h + 2*pad - ks)/stride + 1.  ks in {1,3}; pad = ks/2; cin % 32 == 0, or cin == 4
+ *   (conv1a, RGB + zero channel).  scale/shift = folded eval BatchNorm (NULL = identity). */
+int pram_conv2d_nhwc_f32(const float* in, int batch, int h, int w, int cin, const float* wgt,
+                         const float* bias, const float* scale, const float* shift,
+                         const float* residual, float* out, int cout, int ks, int stride, int relu,
+                         void* stream);
+
+/* Grouped 3x3 convolution of the ResBlock (groups = 32, 8 ch/group; nets/sfd2.py:98-99,113-115).
+ * w [c][3][3][c/groups]. */
+int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int c, const float* wgt,
+                                  const float* scale, const float* shift, float* out, int groups,
+                                  int relu, void* stream);
+
+/* NCHW [b][3][h][w] -> NHWC4 [b][h][w][4] (zero 4th channel) */
+int pram_image_to_nhwc4_f32(const float* img, float* out, int batch, int h, int w, void* stream);
+/* NHWC [b][h][w][c] -> NCHW [b][c][h][w] (for the reference-layout dict entries) */
+int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int h, int w, int c, void* stream);
+
+/* softmax over 65 channels, drop dustbin, 8x8 depth-to-space (nets/sfd2.py:294-300; K2).
+ * logits NHWC [b][hc][wc][65] -> score [b][8hc][8wc] */
+int pram_score_map_f32(const float* logits, float* score, int batch, int hc, int wc, void* stream);
+
+/* simple_nms (nets/sfd2.py:20-35; K3): 1 + 2 suppression rounds, window 2r+1, exact equality. */
+int pram_simple_nms_f32(const float* score, float* nms, int batch, int h, int w, int radius,
+                        void* stream);
+
+size_t pram_select_keypoints_workspace_bytes(int batch, int h, int w, int max_keypoints);
+
+/* threshold / min-keypoint fallback / remove_borders / top-k (nets/sfd2.py:306-329,38-50; K4).
+ * Canonical order: if more than max_keypoints candidates survive, (score desc, flat index asc);
+ * otherwise row-major.  fallback_ref: -1 = each image tests its own count (per-query
+ * semantics), >= 0 = every image uses that image's count (reference tests element 0).
+ * kpts [b][max_keypoints][2] (x,y) fp32, scores [b][max_keypoints], counts [b]. */
+int pram_select_keypoints_f32(const float* nms, int batch, int h, int w, float conf_th,
+                              int min_keypoints, int border, int max_keypoints, int fallback_ref,
+                              float* kpts, float* scores, int* counts, void* workspace, void* stream);
+
+/* sample_descriptors / ResNet4x.sample (nets/sfd2.py:53-64,348-369; K5): bilinear
+ * grid_sample(align_corners=True, zero pad) of an NHWC map at keypoints, optional L2 norm,
+ * optional per-pixel pre-normalisation of the map taps is NOT applied (pass a normalised map).
+ * fmap [b][fh][fw][c]; kpts [b][n_max][2]; out [b][n_max][c].  c in {128, 256}. */
+int pram_sample_nhwc_f32(const float* fmap, int batch, int fh, int fw, int c, const float* kpts,
+                         const int* lens, int n_max, int s, int l2norm, float* out, void* stream);
+
+/* F.normalize(x, dim=channel) of an NHWC map in place (nets/sfd2.py:333). rows = b*h*w */
+int pram_l2norm_rows_f32(float* x, int rows, int cols, void* stream);
+
+/* score lookup of ResNet4x.sample (nets/sfd2.py:367): out[b][i] = score_map[b*map_stride + y_i*w + x_i]
+ * (map_stride = 0 reproduces the reference's score_map[0, ...]) */
+int pram_score_lookup_f32(const float* score_map, long long map_stride, int h, int w, const float* kpts,
+                          const int* lens, int batch, int n_max, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRAM_HIP_H */

@@ -1,0 +1,336 @@
+"""ORACLE TOOLING — runs ONLY in the build container (needs /root/reference; never on the GPU box).
+
+Imports the reference PRAM code (read-only, with the two harness-side shims of SURVEY.md H5/H6),
+loads the build's deterministic weights into the reference modules with ``strict=True`` (which
+proves state-dict schema compatibility), runs the reference on CPU fp32, checks the CPU
+restatement ``oracle/ref_cpu.py`` against it, and writes small golden fixtures to
+``tests/golden/*.npz``.  Fixtures hold data only: seeds/sizes, outputs (sub-sampled where large)
+and checksums; inputs and weights are regenerated from ``pram_amd.weights``.
+
+    python oracle/gen_golden.py            # regenerate everything
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+OUT = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref_cpu as R  # noqa: E402
+from pram_amd import weights as W  # noqa: E402
+
+
+def import_reference():
+    """Shim H6: stub torchvision.transforms.{Compose,Normalize}; shim H5: CPU sink_algorithm for adagml."""
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvt = types.ModuleType("torchvision.transforms")
+
+        class Normalize:
+            def __init__(self, mean, std):
+                self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+            def __call__(self, x):
+                return (x - self.mean) / self.std
+
+        class Compose:
+            def __init__(self, ts):
+                self.ts = ts
+
+            def __call__(self, x):
+                for t in self.ts:
+                    x = t(x)
+                return x
+
+        tvt.Normalize, tvt.Compose = Normalize, Compose
+        tv.transforms = tvt
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.transforms"] = tvt
+    sys.path.insert(0, str(REF))
+    import nets.sfd2 as ref_sfd2
+    import nets.segnetvit as ref_segvit
+    import nets.load_segnet as ref_load
+    import nets.gml as ref_gml
+    import nets.adagml as ref_adagml
+    import nets.utils as ref_utils
+    ref_adagml.sink_algorithm = ref_gml.sink_algorithm
+    return dict(sfd2=ref_sfd2, segvit=ref_segvit, load=ref_load, gml=ref_gml, adagml=ref_adagml, utils=ref_utils)
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def sub(t: torch.Tensor, n: int = 4096):
+    """Deterministic sub-sample (every k-th flat element) + checksum of the full tensor."""
+    f = t.reshape(-1).double()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].float().numpy(), np.array([f.sum().item(), f.abs().sum().item()])
+
+
+def save(name, **arrs):
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / f"{name}.npz", **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote tests/golden/{name}.npz ({(OUT / f'{name}.npz').stat().st_size / 1024:.1f} KiB)")
+
+
+def gen_segnetvit(ref):
+    print("SegNetViT")
+    for tag, (B, N, C) in {"b2_n512_c113": (2, 512, 113), "b1_n300_c161": (1, 300, 161)}.items():
+        model = ref["load"].load_segnet("segnetvit", C, 256, 15, 1024).eval()
+        sd = W.make_state_dict("segnetvit", model.state_dict(), seed=7)
+        model.load_state_dict(sd, strict=True)
+        toks = [W.synthetic_tokens(i, N) for i in range(B)]
+        desc = torch.stack([t[0] for t in toks])
+        kp = torch.stack([t[1] for t in toks])
+        img = torch.empty(B, 3, 480, 640)
+        with torch.no_grad():
+            out_ref = model({"seg_descriptors": desc, "keypoints": kp, "image": img})["prediction"]
+            probes = {}
+            out_or = R.segnetvit_forward(sd, desc, kp, img.shape, probes=probes)
+        d = maxdiff(out_ref, out_or)
+        print(f"  {tag}: |ref - oracle|max = {d:.3e}  logits range [{out_ref.min():.3f},{out_ref.max():.3f}]"
+              f"  argmax classes used {out_ref.argmax(-1).unique().numel()}")
+        assert d < 2e-5, d
+        s, cs = sub(out_ref, 8192)
+        l0, _ = sub(probes["layer0"], 2048)
+        save(f"segnetvit_{tag}", B=B, N=N, C=C, seed=7, logits_sub=s, logits_checksum=cs,
+             argmax=out_ref.argmax(-1).numpy().astype(np.int16), layer0_sub=l0,
+             logits_rows=out_ref[:, :8].numpy())
+
+
+def gen_sinkhorn(ref):
+    print("Sinkhorn / dual-softmax / compute_matches")
+    g = ref["gml"]
+    for tag, (m, n) in {"257x193": (257, 193), "100x300": (100, 300)}.items():
+        M = W.normal(11, f"sink/{tag}", (2, m, n), 2.0)
+        # plant a permutation signal so argmax / mutual checks are non-trivial
+        for b in range(2):
+            idx = torch.argsort(W.uniform(12 + b, f"sink/perm/{tag}", (m,)))[: min(m, n)]
+            M[b, idx, torch.arange(min(m, n))] += 6.0
+        bin_score = torch.tensor(1.0)
+        with torch.no_grad():
+            p_ref = g.sink_algorithm(M, bin_score, 20)
+            p_or = R.sink_algorithm(M, bin_score, 20)
+            ds_ref = g.dual_softmax(M, bin_score)
+            ds_or = R.dual_softmax(M, bin_score)
+            net = g.GML({})
+            res = {}
+            for p in (0.0, 0.2):
+                i0, i1, s0, s1 = net.compute_matches(p_ref, p)
+                o0, o1, t0, t1 = R.compute_matches(p_or, p)
+                assert torch.equal(i0, o0) and torch.equal(i1, o1), "compute_matches indices differ"
+                assert maxdiff(s0, t0) < 1e-6 and maxdiff(s1, t1) < 1e-6
+                res[p] = (i0, i1, s0, s1)
+        print(f"  {tag}: sinkhorn diff {maxdiff(p_ref, p_or):.2e}  dual diff {maxdiff(ds_ref, ds_or):.2e} "
+              f" matches(p=0.2) {(res[0.2][0] >= 0).sum().item()}")
+        assert maxdiff(p_ref, p_or) < 1e-6 and maxdiff(ds_ref, ds_or) < 1e-6
+        save(f"sinkhorn_{tag}", m=m, n=n, p=p_ref.numpy(), dual=ds_ref.numpy(),
+             m0_p0=res[0.0][0].numpy().astype(np.int32), m1_p0=res[0.0][1].numpy().astype(np.int32),
+             m0_p02=res[0.2][0].numpy().astype(np.int32), m1_p02=res[0.2][1].numpy().astype(np.int32),
+             s0=res[0.0][2].numpy(), s1=res[0.0][3].numpy())
+
+
+def _pair_data(idx, m, n, shape_key="image_shape"):
+    d = W.synthetic_match_pair(idx, m, n)
+    data = {k + "": v[None] for k, v in d.items() if k != "gt"}
+    if shape_key == "image_shape":
+        data["image_shape0"] = (1, 3, 640, 480)   # (W,H)-swapped tuple exactly as singlemap3d.py:147 passes it
+        data["image_shape1"] = (1, 3, 640, 480)
+    else:
+        data["image0"] = torch.empty(1, 1, 480, 640)
+        data["image1"] = torch.empty(1, 1, 480, 640)
+    return data, d["gt"]
+
+
+def gen_gml(ref):
+    print("GML")
+    g = ref["gml"]
+    net = g.GML({}).eval()
+    sd = W.make_state_dict("gml", net.state_dict(), seed=7)
+    net.load_state_dict(sd, strict=True)
+    for tag, (m, n, key) in {"m384_n512": (384, 512, "image_shape"), "m256_n256_img": (256, 256, "image")}.items():
+        data, gt = _pair_data(0, m, n, key)
+        with torch.no_grad():
+            r_def = net(data)
+            r_p0 = net.produce_matches(data, p=0.0)
+            probes = {}
+            o_def = R.gml_produce_matches(sd, data, p=0.2, probes=probes)
+            o_p0 = R.gml_produce_matches(sd, data, p=0.0)
+        for a, b in ((r_def, o_def), (r_p0, o_p0)):
+            for k in ("matches0", "matches1"):
+                assert torch.equal(a[k], b[k]), f"{tag} {k} differs from oracle"
+            for k in ("matching_scores0", "matching_scores1"):
+                assert maxdiff(a[k], b[k]) < 1e-5, (tag, k, maxdiff(a[k], b[k]))
+        nm = (r_def["matches0"] >= 0).sum().item()
+        nm0 = (r_p0["matches0"] >= 0).sum().item()
+        correct = ((r_p0["matches0"][0] == gt) & (gt >= 0)).sum().item()
+        print(f"  {tag}: matches p=0.2: {nm}, p=0: {nm0} (gt-consistent {correct}); max score {r_p0['matching_scores0'].max():.3f}")
+        ds, dcs = sub(probes["dist"], 4096)
+        save(f"gml_{tag}", m=m, n=n, key=key, seed=7,
+             m0_def=r_def["matches0"].numpy().astype(np.int32), m1_def=r_def["matches1"].numpy().astype(np.int32),
+             m0_p0=r_p0["matches0"].numpy().astype(np.int32), m1_p0=r_p0["matches1"].numpy().astype(np.int32),
+             s0=r_p0["matching_scores0"].numpy(), s1=r_p0["matching_scores1"].numpy(),
+             dist_sub=ds, dist_checksum=dcs, desc0_sub=sub(probes["desc0"], 2048)[0])
+    # wrapper path: dynamic_load -> strict state-dict load -> forward
+    import localization.matchers as ref_matchers
+    from localization.base_model import dynamic_load
+    with tempfile.TemporaryDirectory() as td:
+        wp = os.path.join(td, "gml.pth")
+        torch.save({"model": sd}, wp)
+        Model = dynamic_load(ref_matchers, "gml")
+        wrapped = Model({"name": "gml", "weight_path": wp, "sinkhorn_iterations": 20}).eval()
+        data, _ = _pair_data(0, 384, 512)
+        with torch.no_grad():
+            rw = wrapped(data)
+        g0 = np.load(OUT / "gml_m384_n512.npz")
+        assert np.array_equal(rw["matches0"].numpy().astype(np.int32), g0["m0_def"])
+        print("  wrapper path (dynamic_load + strict load) reproduces the direct call")
+
+
+def gen_adagml(ref):
+    print("AdaGML")
+    a = ref["adagml"]
+    net = a.AdaGML({}).eval()
+    sd = W.make_state_dict("adagml", net.state_dict(), seed=7)
+    net.load_state_dict(sd, strict=True)
+    for tag, (m, n, pidx) in {"m640_n768": (640, 768, 1), "m300_n280": (300, 280, 2)}.items():
+        data, gt = _pair_data(pidx, m, n)
+        with torch.no_grad():
+            r = net.produce_matches(data, p=0.0)
+            probes = {}
+            o = R.adagml_produce_matches(sd, data, p=0.0, probes=probes)
+        assert torch.equal(r["matches0"], o["matches0"]), "adagml matches0 differs from oracle"
+        assert maxdiff(r["matching_scores0"], o["matching_scores0"]) < 1e-5
+        print(f"  {tag}: stop layer {probes['stop_layer']}, sizes {probes['sizes']}, "
+              f"matches {(r['matches0'] >= 0).sum().item()}")
+        save(f"adagml_{tag}", m=m, n=n, seed=7, pair_index=pidx, m0_p0=r["matches0"].numpy().astype(np.int32),
+             s0=r["matching_scores0"].numpy(), stop_layer=probes["stop_layer"],
+             ind0=probes["ind0"].numpy().astype(np.int32), ind1=probes["ind1"].numpy().astype(np.int32),
+             sizes=np.array(probes["sizes"], dtype=np.int32), conf0_l0=probes["conf0_0"].numpy(),
+             conf0_l1=probes["conf0_1"].numpy())
+
+
+def gen_normalize(ref):
+    print("normalize_keypoints (W,H)-swap quirk")
+    k = torch.tensor([[[0.0, 0.0], [320.0, 240.0], [639.0, 479.0]]])
+    a = ref["utils"].normalize_keypoints(k, (1, 3, 480, 640))
+    b = ref["utils"].normalize_keypoints(k, (1, 3, 640, 480))
+    assert maxdiff(a, R.normalize_keypoints(k, (1, 3, 480, 640))) < 1e-7
+    assert maxdiff(b, R.normalize_keypoints(k, (1, 3, 640, 480))) < 1e-7
+    save("normalize_keypoints", kpts=k.numpy(), hw_480_640=a.numpy(), hw_640_480=b.numpy())
+
+
+def gen_sfd2(ref):
+    print("SFD2")
+    s = ref["sfd2"]
+    net = s.ResNet4x(3, 128).eval()
+    sd = W.make_state_dict("sfd2", net.state_dict(), seed=7)
+    net.load_state_dict(sd, strict=True)
+    # (1) full frame 480x640, k = 2048
+    img = W.synthetic_image(0)[None]
+    cfg = {"min_keypoints": 128, "max_keypoints": 2048}
+    with torch.no_grad():
+        r = net.extract_local_global({"image": img.clone()}, cfg)
+        o = R.sfd2_extract_local_global(sd, img, max_keypoints=2048)
+    for k in ("score_map", "desc_map", "mid_features"):
+        print(f"  {k}: |ref-oracle| = {maxdiff(r[k], o[k]):.2e}  range [{r[k].min():.4f}, {r[k].max():.4f}]")
+        assert maxdiff(r[k], o[k]) < 1e-5
+    # canonicalise the reference's topk order (ties unspecified): sort by (score desc, flat idx asc)
+    kp_r, sc_r = r["keypoints"][0], r["scores"][0]
+    flat = (kp_r[:, 1] * 640 + kp_r[:, 0]).long()
+    order = np.lexsort((flat.numpy(), -sc_r.numpy().astype(np.float64)))
+    kp_rc, sc_rc = kp_r[order], sc_r[order]
+    n_ties = int((sc_rc[1:] == sc_rc[:-1]).sum())
+    n_cand = int((R.simple_nms(r["score_map"], 4) >= 0.005).sum())
+    print(f"  keypoints {tuple(kp_r.shape)}, candidates {n_cand}, exact score ties among selected {n_ties}")
+    assert torch.equal(kp_rc, o["keypoints"][0]) and torch.equal(sc_rc, o["scores"][0]), "keypoint set differs"
+    d_r = r["descriptors"][0][:, order]
+    assert maxdiff(d_r, o["descriptors"][0]) < 1e-5
+    with torch.no_grad():
+        sc2, seg = net.sample(r["score_map"], r["mid_features"], kp_rc, norm_desc=False)
+        sc2o, sego = R.sfd2_sample(o["score_map"], o["mid_features"], o["keypoints"][0], norm_desc=False)
+    assert maxdiff(seg, sego) < 1e-5 and torch.equal(sc2, sc2o)
+    nms_ref = s.simple_nms(r["score_map"], 4)
+    assert torch.equal(nms_ref, o["nms"])
+    save("sfd2_frame0", seed=7, H=480, W=640, k=2048,
+         score_sub=sub(r["score_map"], 8192)[0], score_checksum=sub(r["score_map"])[1],
+         out4_sub=sub(r["mid_features"], 8192)[0], out4_checksum=sub(r["mid_features"])[1],
+         desc_map_sub=sub(r["desc_map"], 8192)[0],
+         keypoints=kp_rc.numpy().astype(np.int16), scores=sc_rc.numpy(),
+         descriptors_sub=d_r[:, ::16].numpy(), seg_desc_sub=seg[:, ::16].numpy(),
+         nms_nonzero=torch.nonzero(nms_ref[0]).numpy().astype(np.int16), n_candidates=n_cand)
+    # (2) small frames: batch of 2 (fallback looks at element 0 only), min_keypoints fallback, k > candidates
+    img2 = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)])
+    for tag, cfgx in {"small_k64": dict(max_keypoints=64, min_keypoints=8),
+                      "small_fallback": dict(max_keypoints=4096, min_keypoints=100000),
+                      "small_all": dict(max_keypoints=4096, min_keypoints=0)}.items():
+        with torch.no_grad():
+            r2 = net.extract_local_global({"image": img2.clone()}, cfgx)
+            o2 = R.sfd2_extract_local_global(sd, img2, **cfgx)
+        arrs = {}
+        for b in range(2):
+            kp, sc = r2["keypoints"][b], r2["scores"][b]
+            if len(kp) == cfgx["max_keypoints"]:
+                fl = (kp[:, 1] * 128 + kp[:, 0]).long()
+                od = np.lexsort((fl.numpy(), -sc.numpy().astype(np.float64)))
+                kp, sc = kp[od], sc[od]
+            assert torch.equal(kp, o2["keypoints"][b]) and torch.equal(sc, o2["scores"][b]), (tag, b)
+            arrs[f"kp{b}"] = kp.numpy().astype(np.int16)
+            arrs[f"sc{b}"] = sc.numpy()
+        print(f"  {tag}: counts {[len(k) for k in r2['keypoints']]}")
+        save(f"sfd2_{tag}", **arrs, score_map=r2["score_map"].numpy(), **{k: v for k, v in cfgx.items()})
+    # (3) crafted NMS tie / plateau case
+    sm = torch.zeros(1, 40, 48)
+    sm[0, 10, 10] = 0.5
+    sm[0, 10, 13] = 0.5     # tie inside one window: both are maxima of their windows
+    sm[0, 20:23, 20:23] = 0.3  # plateau
+    sm[0, 30, 5] = 0.2
+    sm[0, 33, 8] = 0.25
+    sm[0, 0, 47] = 0.9
+    sm += W.uniform(5, "nms/noise", (1, 40, 48), 0.0, 0.01)
+    for rad in (3, 4):
+        a = s.simple_nms(sm, rad)
+        assert torch.equal(a, R.simple_nms(sm, rad))
+        save(f"nms_crafted_r{rad}", score=sm.numpy(), nms=a.numpy(), radius=rad)
+
+
+def gen_schema(ref):
+    """State-dict key/shape schema of the reference modules (what load_state_dict(strict=True) needs)."""
+    print("state-dict schema")
+    mods = {
+        "sfd2": ref["sfd2"].ResNet4x(3, 128),
+        "segnetvit_c113": ref["load"].load_segnet("segnetvit", 113, 256, 15, 1024),
+        "gml": ref["gml"].GML({}),
+        "adagml": ref["adagml"].AdaGML({}),
+    }
+    arrs = {}
+    for name, m in mods.items():
+        sd = m.state_dict()
+        arrs[name + "_keys"] = np.array(list(sd.keys()))
+        arrs[name + "_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        print(f"  {name}: {len(sd)} tensors, {sum(v.numel() for v in sd.values())} elements")
+    save("schema", **arrs)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    only = sys.argv[1:] or ["schema", "normalize", "sinkhorn", "segnetvit", "gml", "adagml", "sfd2"]
+    for name in only:
+        globals()[f"gen_{name}"](ref)
+    print("all reference-vs-oracle checks passed; fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

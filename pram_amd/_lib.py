@@ -1,0 +1,80 @@
+"""ctypes binding of libpram_hip.so (the C ABI declared in include/pram_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpram_hip.so"
+_lib = None
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+LL = C.c_longlong
+SZ = C.c_size_t
+
+_SIGS = {
+    "pram_hip_version": (I, []),
+    "pram_last_error": (C.c_char_p, []),
+    "pram_linear_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
+    "pram_bgemm_nt_f32": (I, [P, I, LL, P, I, LL, P, I, LL, I, I, I, I, F, P]),
+    "pram_layernorm_gelu_f32": (I, [P, I, P, I, P, P, I, I, F, P]),
+    "pram_fourier_encoding_f32": (I, [P, P, F, F, F, P, P, I, P]),
+    "pram_attention_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P]),
+    "pram_attention_colmean_f32": (I, [P, I, P, I, P, P, P, P, I, I, I, I, F, P]),
+    "pram_sinkhorn_workspace_bytes": (SZ, [I, I, I]),
+    "pram_sinkhorn_match_f32": (I, [P, I, P, P, P, I, F, P, I, P, P, P, P, I, I, I, P, P]),
+    "pram_dual_softmax_match_f32": (I, [P, I, P, P, P, F, P, I, P, P, P, P, I, I, I, P, P]),
+    "pram_adagml_prune_f32": (I, [P, F, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "pram_adagml_scatter_f32": (I, [P, P, P, P, P, I, I, I, P, P, P]),
+    "pram_conv2d_nhwc_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),
+    "pram_conv3x3_grouped_nhwc_f32": (I, [P, I, I, I, I, P, P, P, P, I, I, P]),
+    "pram_image_to_nhwc4_f32": (I, [P, P, I, I, I, P]),
+    "pram_nhwc_to_nchw_f32": (I, [P, P, I, I, I, I, P]),
+    "pram_score_map_f32": (I, [P, P, I, I, I, P]),
+    "pram_simple_nms_f32": (I, [P, P, I, I, I, I, P]),
+    "pram_select_keypoints_workspace_bytes": (SZ, [I, I, I, I]),
+    "pram_select_keypoints_f32": (I, [P, I, I, I, F, I, I, I, I, P, P, P, P, P]),
+    "pram_sample_nhwc_f32": (I, [P, I, I, I, I, P, P, I, I, I, P, P]),
+    "pram_l2norm_rows_f32": (I, [P, I, I, P]),
+    "pram_score_lookup_f32": (I, [P, LL, I, I, P, P, I, I, P, P]),
+}
+
+
+class PramHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libpram_hip.so; raises PramHipError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise PramHipError(
+            f"{_LIB_PATH} not found: build it with `python -m pram_amd.build` "
+            "(pram_amd has no CPU / eager fallback)")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().pram_last_error()
+        raise PramHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,309 @@
+// Flash-style multi-head attention in exact fp32 on the gfx950 matrix cores
+// (v_mfma_f32_32x32x2_f32).  Replaces the materialised einsum -> softmax -> einsum of
+// nets/segnetvit.py:73-76 (self), nets/gml.py:175-179 (cross; two calls) and the column means of
+// nets/adagml.py:148,229.
+//
+// Work decomposition: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave
+// owns 32 query rows and walks the keys in tiles of 64 staged through LDS (K XOR-swizzled for
+// conflict-free ds_read_b128, V linear for conflict-free ds_read_b32), double buffered, one
+// barrier per tile.
+//
+// Register-level layout (the point of the design): everything is computed TRANSPOSED so that
+// the query row is the lane index in every accumulator —
+//   Sᵀ[key][q] = mfma(A = K-fragment, B = Q-fragment): lane (r = l&31, h = l>>5) holds, for
+//       query r, the 16 keys (e&3) + 8(e>>2) + 4h of the 32-key sub-tile;
+//   Oᵀ[d][q]  = mfma(A = Vᵀ-fragment, B = Pᵀ-fragment): the B operand of step e is exactly the
+//       register e of exp(Sᵀ) (lane r supplies P[q = r][key(e, h)]), and the accumulator holds
+//       O[q = r][d(e, h)].
+// So the online-softmax state (row max m, row sum l, rescale factor) is lane-local, P never
+// moves between lanes or through LDS, and the only cross-lane op per tile is one
+// __shfl_xor(…, 32) for the row max.  At the f32 MFMA rate (64 cycles per instruction) the
+// kernel is matrix-pipe bound: 128 MFMA = 8192 cycles per 64-key tile per wave against ~64
+// v_exp + ~200 VALU and 80 LDS reads.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int D = 64;     // head dim (fixed: hidden 256 / 4 heads)
+constexpr int QW = 32;    // query rows per wave
+constexpr int NW = 4;     // waves per workgroup
+constexpr int BQ = QW * NW;
+constexpr int BKV = 64;   // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v;
+    float* out; float* lse2;
+    const int* q_lens; const int* k_lens;
+    int ldq, ldk, ldv, ldo;
+    int batch, heads, m_max, n_max;
+    float scale2;
+    int q_tiles;
+};
+
+struct Smem {
+    float k[2][BKV * D];
+    float v[2][BKV * D];
+};  // 64 KiB -> two workgroups per CU
+
+__device__ __forceinline__ int key_of(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
+    __shared__ Smem s;
+    const int nblk = p.batch * p.heads * p.q_tiles;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int qt = id % p.q_tiles;
+    const int bh = id / p.q_tiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int klen = p.k_lens ? p.k_lens[b] : p.n_max;
+    if (qt * BQ >= qlen || klen <= 0) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qt * BQ + wave * QW;          // first query row of this wave (within batch b)
+    const bool wave_active = q0 < qlen;
+    const int qrow = q0 + r;
+    const bool q_ok = qrow < qlen;
+
+    const float* qp = p.q + ((size_t)b * p.m_max + qrow) * p.ldq + head * D;
+    const float* kp = p.k + (size_t)b * p.n_max * p.ldk + head * D;
+    const float* vp = p.v + (size_t)b * p.n_max * p.ldv + head * D;
+
+    // Q fragments: qf[c] = Q[qrow][8c + 4h .. +3]
+    float4 qf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        qf[c] = q_ok ? *reinterpret_cast<const float4*>(qp + c * 8 + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int lrow = tid >> 4, lslot = tid & 15;   // staging: row lrow + 16p, 16-B slot lslot
+    float4 kr[4], vr[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int key = kt * BKV + lrow + 16 * pp;
+            if (key < klen) {
+                kr[pp] = *reinterpret_cast<const float4*>(kp + (size_t)key * p.ldk + lslot * 4);
+                vr[pp] = *reinterpret_cast<const float4*>(vp + (size_t)key * p.ldv + lslot * 4);
+            } else {
+                kr[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vr[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int row = lrow + 16 * pp;
+            *reinterpret_cast<float4*>(&s.k[buf][row * D + ((lslot ^ (row & 15)) << 2)]) = kr[pp];
+            *reinterpret_cast<float4*>(&s.v[buf][row * D + (lslot << 2)]) = vr[pp];
+        }
+    };
+
+    const int nkt = (klen + BKV - 1) / BKV;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) gload(kt + 1);
+
+        if (wave_active) {
+            // ---- Sᵀ = K · Qᵀ for the two 32-key sub-tiles
+            f32x16 st[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
+            const float* sk = s.k[cur];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int slot = (2 * c + h) ^ (r & 15);   // (key & 15) == (r & 15) for key = 32t + r
+                const float4 k0 = *reinterpret_cast<const float4*>(sk + r * D + (slot << 2));
+                const float4 k1 = *reinterpret_cast<const float4*>(sk + (32 + r) * D + (slot << 2));
+                const float a0[4] = {k0.x, k0.y, k0.z, k0.w};
+                const float a1[4] = {k1.x, k1.y, k1.z, k1.w};
+                const float bq[4] = {qf[c].x, qf[c].y, qf[c].z, qf[c].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[j], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[j], st[1], 0, 0, 0);
+                }
+            }
+            // ---- mask keys beyond klen (last tile only)
+            if (!more && (klen & (BKV - 1))) {
+                const int kbase = kt * BKV;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + t * 32 + key_of(e, h) >= klen) st[t][e] = -INFINITY;
+            }
+            // ---- online softmax, lane-local per query row
+            float tmax = st[0][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax * p.scale2);
+            const float alpha = exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = exp2f(fmaf(st[t][e], p.scale2, -m_new));
+                    st[t][e] = pv;
+                    psum += pv;
+                }
+            l_run = fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+            // ---- Oᵀ += Vᵀ · Pᵀ
+            const float* sv = s.v[cur];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = t * 32 + key_of(e, h);
+                    const float v0 = sv[key * D + r];
+                    const float v1 = sv[key * D + 32 + r];
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[t][e], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[t][e], oacc[1], 0, 0, 0);
+                }
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
+                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
+            }
+        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + log2f(l_tot);
+    }
+}
+
+// ---------------------------------------------------------------- column means (AdaGML)
+// colmean[b][j] = 1/(H * m_b) * sum_h sum_i exp2(scale2 * q_i·k_j - lse2[b,h,i]).
+// One workgroup = 128 keys (32 per wave, K fragments in registers), loops over heads and over
+// 64-row Q tiles staged through LDS.  Sᵀ[key][q]: the query is the lane, the key the register,
+// so the per-key sums accumulate in registers and cross lanes once at the end.
+struct ColArgs {
+    const float* q; const float* k; const float* lse2; float* colmean;
+    const int* q_lens; const int* k_lens;
+    int ldq, ldk, batch, heads, m_max, n_max;
+    float scale2;
+};
+
+__global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
+    __shared__ float sq[BKV * D];
+    const int b = blockIdx.y;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int klen = p.k_lens ? p.k_lens[b] : p.n_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int key0 = blockIdx.x * 128 + wave * 32;
+    if (blockIdx.x * 128 >= klen) return;
+    const int lrow = tid >> 4, lslot = tid & 15;
+    const int nqt = (qlen + BKV - 1) / BKV;
+
+    float cacc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cacc[e] = 0.f;
+
+    for (int head = 0; head < p.heads; ++head) {
+        const int key = key0 + r;
+        const float* kp = p.k + ((size_t)b * p.n_max + key) * p.ldk + head * D;
+        float4 kf[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            kf[c] = (key < klen) ? *reinterpret_cast<const float4*>(kp + c * 8 + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* qbase = p.q + (size_t)b * p.m_max * p.ldq + head * D;
+        const float* lse = p.lse2 + ((size_t)b * p.heads + head) * p.m_max;
+        for (int qt = 0; qt < nqt; ++qt) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int row = lrow + 16 * pp;
+                const int qi = qt * BKV + row;
+                const float4 v = (qi < qlen) ? *reinterpret_cast<const float4*>(qbase + (size_t)qi * p.ldq + lslot * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sq[row * D + ((lslot ^ (row & 15)) << 2)]) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 st;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int slot = (2 * c + h) ^ (r & 15);
+                    const float4 qv = *reinterpret_cast<const float4*>(sq + (t * 32 + r) * D + (slot << 2));
+                    const float a[4] = {kf[c].x, kf[c].y, kf[c].z, kf[c].w};
+                    const float bq[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) st = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bq[j], st, 0, 0, 0);
+                }
+                const int qi = qt * BKV + t * 32 + r;
+                const float l2 = (qi < qlen) ? lse[qi] : INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cacc[e] += exp2f(fmaf(st[e], p.scale2, -l2));
+            }
+            __syncthreads();
+        }
+    }
+    const float norm = 1.0f / ((float)p.heads * (float)qlen);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float v = cacc[e];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int key = key0 + key_of(e, h);
+        if (r == 0 && key < klen) p.colmean[(size_t)b * p.n_max + key] = v * norm;
+    }
+}
+
+}  // namespace
+
+extern "C" int pram_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                  float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens, int batch,
+                                  int heads, int m_max, int n_max, float scale, void* stream) {
+    PRAM_REQUIRE(q && k && v && out, "pram_attention_f32: null pointer");
+    PRAM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "pram_attention_f32: ld must be a multiple of 4");
+    PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0, "pram_attention_f32: bad sizes");
+    if (batch == 0 || m_max == 0) return PRAM_OK;
+    PRAM_REQUIRE(n_max > 0, "pram_attention_f32: empty key set");
+    AttnArgs p{q, k, v, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max, scale * LOG2E,
+               cdiv(m_max, BQ)};
+    hipLaunchKernelGGL(attention_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_f32");
+}
+
+extern "C" int pram_attention_colmean_f32(const float* q, int ldq, const float* k, int ldk, const float* lse2,
+                                          float* colmean, const int* q_lens, const int* k_lens, int batch, int heads,
+                                          int m_max, int n_max, float scale, void* stream) {
+    PRAM_REQUIRE(q && k && lse2 && colmean, "pram_attention_colmean_f32: null pointer");
+    PRAM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0, "pram_attention_colmean_f32: ld must be a multiple of 4");
+    if (batch == 0 || n_max == 0 || m_max == 0) return PRAM_OK;
+    ColArgs p{q, k, lse2, colmean, q_lens, k_lens, ldq, ldk, batch, heads, m_max, n_max, scale * LOG2E};
+    hipLaunchKernelGGL(colmean_kernel, dim3(cdiv(n_max, 128), batch), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_colmean_f32");
+}

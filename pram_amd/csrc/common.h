@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels of libpram_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pram_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void pram_set_error(const char* fmt, ...);
+
+#define PRAM_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            pram_set_error(__VA_ARGS__);   \
+            return PRAM_E_ARG;             \
+        }                                  \
+    } while (0)
+
+static inline int pram_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pram_set_error("%s: %s", what, hipGetErrorString(e));
+        return PRAM_E_LAUNCH;
+    }
+    return PRAM_OK;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; after the
+// remap consecutive logical ids share an XCD (and therefore its L2).  Placement is used for
+// speed only, never for correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,244 @@
+// SFD2 convolution stack (ResNet4x, nets/sfd2.py:135-170,281-293,331-333) as NHWC implicit GEMM
+// on the exact-fp32 matrix cores, plus the grouped 3x3 of the ResBlock on the vector ALU.
+//
+// Implicit GEMM: M = batch*Ho*Wo output pixels (row-major, so 128 consecutive rows of a tile are
+// a run of one image row), N = Cout, K = ks*ks*Cin with K ordered (ky, kx, ci) — the NHWC input
+// makes every K-chunk of 32 a contiguous 128-B read per pixel, and the weights are repacked once
+// on the host to [Cout][ky][kx][Cin].  The A loader does the im2col on the fly (bounds-checked
+// zero padding); everything after that is gemm_core.h.  Eval-mode BatchNorm is applied as a
+// per-channel scale/shift in the epilogue (same op order as conv -> BN), then residual, then ReLU.
+#include "gemm_core.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* in; const float* w; const float* bias; const float* scale; const float* shift;
+    const float* residual; float* out;
+    int batch, h, wd, cin, cout, ks, stride, relu;
+    int ho, wo, m, k;
+    int tiles_m, tiles_n;
+};
+
+template <bool CIN4>
+__global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
+    using namespace gemm;
+    __shared__ Smem smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, skq = tid & 7;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int pad = p.ks >> 1;
+
+    // per-thread staging rows: decompose the output pixel once
+    int iy0[4], ix0[4];
+    const float* base[4];
+    bool ok[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        const int row = row0 + srow + 32 * pp;
+        ok[pp] = row < p.m;
+        const int rr = ok[pp] ? row : 0;
+        const int ox = rr % p.wo;
+        const int t = rr / p.wo;
+        const int oy = t % p.ho;
+        const int b = t / p.ho;
+        iy0[pp] = oy * p.stride - pad;
+        ix0[pp] = ox * p.stride - pad;
+        base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
+    }
+
+    auto la = [&](int pp, int kt) -> float4 {
+        int tap, ci;
+        if (CIN4) {
+            tap = kt * 8 + skq;   // one tap (4 padded channels) per float4
+            ci = 0;
+        } else {
+            const int k = kt * BK;
+            tap = k / p.cin;      // cin % 32 == 0: a chunk never straddles taps
+            ci = k - tap * p.cin + skq * 4;
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[pp] && tap < p.ks * p.ks) {
+            const int ky = tap / p.ks, kx = tap - ky * p.ks;
+            const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
+            if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd)
+                v = *reinterpret_cast<const float4*>(base[pp] + ((size_t)iy * p.wd + ix) * p.cin + ci);
+        }
+        return v;
+    };
+    auto lb = [&](int pp, int kt) -> float4 {
+        const int col = col0 + srow + 32 * pp;
+        const int k = kt * BK + skq * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < p.cout && k < p.k) v = *reinterpret_cast<const float4*>(p.w + (size_t)col * p.k + k);
+        return v;
+    };
+
+    f32x16 acc[2][2];
+    mainloop(smem, la, lb, (p.k + BK - 1) / BK, acc);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = col0 + wn * 64 + ni * 32 + r;
+        if (col >= p.cout) continue;
+        const float bi = p.bias ? p.bias[col] : 0.f;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + wm * 64 + acc_row(mi, e, h);
+                if (row >= p.m) continue;
+                float v = acc[mi][ni][e] + bi;
+                if (p.scale) v = v * sc + sh;
+                if (p.residual) v += p.residual[(size_t)row * p.cout + col];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.out[(size_t)row * p.cout + col] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- grouped 3x3 (VALU)
+// groups = 32, 8 in / 8 out channels per group (72-deep dot products: too thin for MFMA tiles).
+// Workgroup = 64 consecutive pixels x 4 groups (one group per wave, so the 576 weights of a group
+// are wave-uniform and come from LDS as broadcasts); each lane owns one pixel of one group:
+// 9 taps x 2 float4 loads, 576 FMAs, 8 outputs.
+struct GConvArgs {
+    const float* in; const float* w; const float* scale; const float* shift; float* out;
+    int batch, h, wd, c, groups, relu, npix;
+};
+
+__global__ __launch_bounds__(256) void gconv3x3_kernel(GConvArgs p) {
+    __shared__ float sw[4][8 * 72];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y * 4 + wave;
+    // weights of group g: out channels g*8 .. +7, each [3][3][8] = 72 floats, contiguous 576 floats
+    for (int i = lane; i < 576; i += 64) sw[wave][i] = p.w[(size_t)g * 576 + i];
+    __syncthreads();
+    const int pix = blockIdx.x * 64 + lane;
+    if (pix >= p.npix) return;
+    const int x = pix % p.wd;
+    const int t = pix / p.wd;
+    const int y = t % p.h;
+    const int b = t / p.h;
+    const float* ib = p.in + (size_t)b * p.h * p.wd * p.c + g * 8;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = x + kx - 1;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd) {
+                const float* src = ib + ((size_t)iy * p.wd + ix) * p.c;
+                a0 = *reinterpret_cast<const float4*>(src);
+                a1 = *reinterpret_cast<const float4*>(src + 4);
+            }
+            const float xin[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float* wt = &sw[wave][(ky * 3 + kx) * 8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[o] = fmaf(xin[i], wt[o * 72 + i], acc[o]);
+        }
+    }
+    float res[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int ch = g * 8 + o;
+        float v = acc[o];
+        if (p.scale) v = v * p.scale[ch] + p.shift[ch];
+        if (p.relu) v = fmaxf(v, 0.f);
+        res[o] = v;
+    }
+    float* dst = p.out + (size_t)pix * p.c + g * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+}
+
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int hw, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / hw, px = i - b * hw;
+    const float* s = img + (size_t)b * 3 * hw + px;
+    *reinterpret_cast<float4*>(out + (size_t)i * 4) = make_float4(s[0], s[hw], s[2 * hw], 0.f);
+}
+
+// NHWC -> NCHW through a 32x33 LDS tile (coalesced both ways)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int hw, int c) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int px = p0 + j, ch = c0 + tx;
+        tile[j][tx] = (px < hw && ch < c) ? in[((size_t)b * hw + px) * c + ch] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int ch = c0 + j, px = p0 + tx;
+        if (px < hw && ch < c) out[((size_t)b * c + ch) * hw + px] = tile[tx][j];
+    }
+}
+
+}  // namespace
+
+extern "C" int pram_conv2d_nhwc_f32(const float* in, int batch, int h, int w, int cin, const float* wgt,
+                                    const float* bias, const float* scale, const float* shift, const float* residual,
+                                    float* out, int cout, int ks, int stride, int relu, void* stream) {
+    PRAM_REQUIRE(in && wgt && out, "pram_conv2d_nhwc_f32: null pointer");
+    PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_f32: ks must be 1 or 3");
+    PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_f32: stride must be 1 or 2");
+    PRAM_REQUIRE(cin == 4 || cin % 32 == 0, "pram_conv2d_nhwc_f32: cin=%d must be 4 or a multiple of 32", cin);
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_f32: scale and shift go together");
+    if (batch == 0) return PRAM_OK;
+    const int pad = ks / 2;
+    ConvArgs p{in, wgt, bias, scale, shift, residual, out, batch, h, w, cin, cout, ks, stride, relu};
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    p.m = batch * p.ho * p.wo;
+    p.k = ks * ks * cin;
+    p.tiles_m = cdiv(p.m, gemm::BM);
+    p.tiles_n = cdiv(cout, gemm::BN);
+    dim3 grid(p.tiles_m * p.tiles_n), blk(gemm::NT);
+    if (cin == 4) hipLaunchKernelGGL(conv_kernel<true>, grid, blk, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_kernel<false>, grid, blk, 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_conv2d_nhwc_f32");
+}
+
+extern "C" int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int c, const float* wgt,
+                                             const float* scale, const float* shift, float* out, int groups, int relu,
+                                             void* stream) {
+    PRAM_REQUIRE(in && wgt && out, "pram_conv3x3_grouped_nhwc_f32: null pointer");
+    PRAM_REQUIRE(groups > 0 && c == groups * 8 && groups % 4 == 0, "pram_conv3x3_grouped_nhwc_f32: needs 8 channels per group");
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv3x3_grouped_nhwc_f32: scale and shift go together");
+    if (batch == 0) return PRAM_OK;
+    GConvArgs p{in, wgt, scale, shift, out, batch, h, w, c, groups, relu, batch * h * w};
+    hipLaunchKernelGGL(gconv3x3_kernel, dim3(cdiv(p.npix, 64), groups / 4), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_conv3x3_grouped_nhwc_f32");
+}
+
+extern "C" int pram_image_to_nhwc4_f32(const float* img, float* out, int batch, int h, int w, void* stream) {
+    PRAM_REQUIRE(img && out, "pram_image_to_nhwc4_f32: null pointer");
+    const int total = batch * h * w;
+    if (total == 0) return PRAM_OK;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, h * w, total);
+    return pram_launch_status("pram_image_to_nhwc4_f32");
+}
+
+extern "C" int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int h, int w, int c, void* stream) {
+    PRAM_REQUIRE(in && out, "pram_nhwc_to_nchw_f32: null pointer");
+    if (batch == 0) return PRAM_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(h * w, 32), cdiv(c, 32), batch), dim3(256), 0, (hipStream_t)stream, in,
+                       out, h * w, c);
+    return pram_launch_status("pram_nhwc_to_nchw_f32");
+}

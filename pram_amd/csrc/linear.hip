@@ -1,0 +1,206 @@
+// Token-side linear algebra: nn.Linear (+concat input, +bias, +alpha, +residual, +rotary
+// epilogue), batched A·Bᵀ, LayerNorm+GELU, Fourier positional encoding.
+// Reference sites: nets/segnetvit.py:87-106,157-164; nets/gml.py:118-186,220,235,278-282.
+#include "gemm_core.h"
+
+namespace {
+
+struct LinArgs {
+    const float* a0; int lda0; int k0;
+    const float* a1; int lda1; int k1;
+    const float* w;
+    const float* bias;
+    const float* residual; int ldr;
+    float* out; int ldo;
+    int m, n;
+    float alpha;
+    int flags;
+    const float* rcos; const float* rsin; int rot_cols;
+    // batching (bgemm): per-z strides in floats; 0 for plain linear
+    long long sa, sw, so;
+    int tiles_m, tiles_n;
+};
+
+__global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
+    using namespace gemm;
+    __shared__ Smem smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int z = blockIdx.y;
+    const float* a0 = p.a0 + z * p.sa;
+    const float* w = p.w + z * p.sw;
+    float* out = p.out + z * p.so;
+    const int K = p.k0 + p.k1;
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, skq = tid & 7;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    auto la = [&](int pp, int kt) -> float4 {
+        const int row = row0 + srow + 32 * pp;
+        const int k = kt * BK + skq * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < p.m && k < K) {
+            const float* src = (k < p.k0) ? (a0 + (size_t)row * p.lda0 + k)
+                                          : (p.a1 + (size_t)row * p.lda1 + (k - p.k0));
+            v = *reinterpret_cast<const float4*>(src);
+        }
+        return v;
+    };
+    auto lb = [&](int pp, int kt) -> float4 {
+        const int col = col0 + srow + 32 * pp;
+        const int k = kt * BK + skq * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < p.n && k < K) v = *reinterpret_cast<const float4*>(w + (size_t)col * K + k);
+        return v;
+    };
+
+    f32x16 acc[2][2];
+    mainloop(smem, la, lb, (K + BK - 1) / BK, acc);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int cbase = col0 + wn * 64;
+    const bool rot = (p.flags & PRAM_LIN_ROTARY) && cbase < p.rot_cols;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = row0 + wm * 64 + acc_row(mi, e, h);
+            if (row >= p.m) continue;
+            float v0 = acc[mi][0][e], v1 = acc[mi][1][e];
+            const int c0 = cbase + r, c1 = cbase + 32 + r;
+            if (p.bias) {
+                if (c0 < p.n) v0 += p.bias[c0];
+                if (c1 < p.n) v1 += p.bias[c1];
+            }
+            v0 *= p.alpha;
+            v1 *= p.alpha;
+            if (rot) {
+                const float c = p.rcos[(size_t)row * 32 + r], s = p.rsin[(size_t)row * 32 + r];
+                const float e0 = v0 * c - v1 * s;   // even dim: t0*cos + (-t1)*sin
+                const float o0 = v1 * c + v0 * s;   // odd dim : t1*cos + t0*sin
+                v0 = e0;
+                v1 = o0;
+            }
+            if (p.residual) {
+                if (c0 < p.n) v0 += p.residual[(size_t)row * p.ldr + c0];
+                if (c1 < p.n) v1 += p.residual[(size_t)row * p.ldr + c1];
+            }
+            if (c0 < p.n) out[(size_t)row * p.ldo + c0] = v0;
+            if (c1 < p.n) out[(size_t)row * p.ldo + c1] = v1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm + GELU
+// One wave per row; the row (<= 1024 floats) lives in registers, mean then centred variance
+// (two-pass, like torch's RowwiseMoments result to fp32 rounding), exact erf GELU.
+template <int NV>  // float4 per lane
+__global__ __launch_bounds__(256) void ln_gelu_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                      int ldy, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (c < cols) ? *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c) : make_float4(0, 0, 0, 0);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4*>(beta + c);
+            float t[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                          (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = 0.5f * t[j] * (1.0f + erff(t[j] * 0.70710678118654752440f));
+            *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- Fourier positional encoding
+__global__ void fourier_kernel(const float* __restrict__ kpts, const float* __restrict__ wr, float cx, float cy,
+                               float scale, float* __restrict__ co, float* __restrict__ si, int rows) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = idx >> 5, f = idx & 31;
+    if (row >= rows) return;
+    const float x = (kpts[row * 2 + 0] - cx) / scale;
+    const float y = (kpts[row * 2 + 1] - cy) / scale;
+    const float pr = x * wr[f * 2 + 0] + y * wr[f * 2 + 1];
+    co[idx] = cosf(pr);
+    si[idx] = sinf(pr);
+}
+
+}  // namespace
+
+extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                               const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                               float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                               void* stream) {
+    PRAM_REQUIRE(a0 && w && out, "pram_linear_f32: null pointer");
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "pram_linear_f32: bad sizes m=%d n=%d k0=%d k1=%d", m, n, k0, k1);
+    PRAM_REQUIRE((k0 + k1) % 4 == 0 && lda0 % 4 == 0, "pram_linear_f32: K and lda must be multiples of 4");
+    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemm::BK == 0 && lda1 % 4 == 0), "pram_linear_f32: concat needs k0 %% 32 == 0");
+    if (flags & PRAM_LIN_ROTARY)
+        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
+    if (m == 0) return PRAM_OK;
+    LinArgs p{a0, lda0, k0, a1, lda1, k1, w, bias, residual, ldr, out, ldo, m, n, alpha, flags,
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, cdiv(m, gemm::BM), cdiv(n, gemm::BN)};
+    hipLaunchKernelGGL(linear_kernel, dim3(p.tiles_m * p.tiles_n, 1), dim3(gemm::NT), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_linear_f32");
+}
+
+extern "C" int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
+                                 long long stride_b, float* c, int ldc, long long stride_c, int batch, int m_max,
+                                 int n_max, int k, float alpha, void* stream) {
+    PRAM_REQUIRE(a && b && c, "pram_bgemm_nt_f32: null pointer");
+    PRAM_REQUIRE(k % 4 == 0 && lda % 4 == 0 && ldb == k, "pram_bgemm_nt_f32: need k %% 4 == 0, lda %% 4 == 0, ldb == k");
+    if (batch == 0 || m_max == 0 || n_max == 0) return PRAM_OK;
+    LinArgs p{a, lda, k, nullptr, 0, 0, b, nullptr, nullptr, 0, c, ldc, m_max, n_max, alpha, 0,
+              nullptr, nullptr, 0, stride_a, stride_b, stride_c, cdiv(m_max, gemm::BM), cdiv(n_max, gemm::BN)};
+    hipLaunchKernelGGL(linear_kernel, dim3(p.tiles_m * p.tiles_n, batch), dim3(gemm::NT), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_bgemm_nt_f32");
+}
+
+extern "C" int pram_layernorm_gelu_f32(const float* x, int ldx, float* y, int ldy, const float* gamma,
+                                       const float* beta, int rows, int cols, float eps, void* stream) {
+    PRAM_REQUIRE(x && y && gamma && beta, "pram_layernorm_gelu_f32: null pointer");
+    PRAM_REQUIRE(cols > 0 && cols <= 1024 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
+                 "pram_layernorm_gelu_f32: cols=%d must be <= 1024 and a multiple of 4", cols);
+    if (rows == 0) return PRAM_OK;
+    dim3 grid(cdiv(rows, 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (cols <= 256) hipLaunchKernelGGL(ln_gelu_kernel<1>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps);
+    else if (cols <= 512) hipLaunchKernelGGL(ln_gelu_kernel<2>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps);
+    else hipLaunchKernelGGL(ln_gelu_kernel<4>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps);
+    return pram_launch_status("pram_layernorm_gelu_f32");
+}
+
+extern "C" int pram_fourier_encoding_f32(const float* kpts, const float* wr, float cx, float cy, float scale,
+                                         float* cos_out, float* sin_out, int rows, void* stream) {
+    PRAM_REQUIRE(kpts && wr && cos_out && sin_out, "pram_fourier_encoding_f32: null pointer");
+    if (rows == 0) return PRAM_OK;
+    hipLaunchKernelGGL(fourier_kernel, dim3(cdiv(rows * 32, 256)), dim3(256), 0, (hipStream_t)stream, kpts, wr, cx, cy,
+                       scale, cos_out, sin_out, rows);
+    return pram_launch_status("pram_fourier_encoding_f32");
+}

@@ -1,0 +1,468 @@
+// SFD2 detector post-processing: score map, NMS, keypoint selection, descriptor sampling.
+// Reference: nets/sfd2.py:20-64 (simple_nms, remove_borders, top_k_keypoints, sample_descriptors),
+// :294-329 (softmax / depth-to-space / threshold / fallback), :348-369 (ResNet4x.sample).
+// All HBM/latency-bound integer-and-compare work; results are bit-exact given the same score map.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ---------------------------------------------------------------- K2: softmax65 + depth-to-space
+// one wave per 8x8 cell: lane c holds channel c, lane 0 also the dustbin channel 64.
+__global__ __launch_bounds__(256) void score_map_kernel(const float* __restrict__ logits, float* __restrict__ score,
+                                                        int hc, int wc, int ncell) {
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= ncell) return;
+    const float* src = logits + (size_t)cell * 65;
+    const float x = src[lane];
+    const float xd = src[64];
+    const float mx = fmaxf(wave_max(x), xd);
+    const float e = expf(x - mx);
+    const float sum = wave_sum(e) + expf(xd - mx);
+    const int cx = cell % wc;
+    const int t = cell / wc;
+    const int cy = t % hc;
+    const int b = t / hc;
+    const int W = wc * 8;
+    score[((size_t)b * hc * 8 + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)] = e / sum;
+}
+
+// ---------------------------------------------------------------- K3: simple_nms
+// One workgroup = 32x32 output pixels; the five chained (2r+1)^2 max-pools need a 5r halo, all of
+// it staged in LDS once and consumed by separable row/column passes.  Out-of-image pixels are -inf
+// in score buffers and 0 in masks (max_pool2d's implicit padding); values whose window leaves the
+// staged tile are garbage but only ever feed other garbage — the central 32x32 is exact.
+constexpr int NMS_T = 32;
+constexpr int NMS_RMAX = 4;
+constexpr int NMS_S = NMS_T + 10 * NMS_RMAX;  // 72
+
+struct NmsSmem {
+    float s[NMS_S * NMS_S];   // scores
+    float x[NMS_S * NMS_S];   // pool input (mask as 0/1, or suppressed scores)
+    float t[NMS_S * NMS_S];   // row-pass temp
+    float p[NMS_S * NMS_S];   // pool output
+    unsigned char mask[NMS_S * NMS_S];
+    unsigned char supp[NMS_S * NMS_S];
+    unsigned char inside[NMS_S * NMS_S];
+};
+
+__device__ __forceinline__ void nms_pool(const float* __restrict__ src, float* __restrict__ tmp, float* __restrict__ dst,
+                                         int side, int r) {
+    const int n = side * side;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / side, x = i - y * side;
+        float m = -INFINITY;
+        const int lo = max(0, x - r), hi = min(side - 1, x + r);
+        for (int xx = lo; xx <= hi; ++xx) m = fmaxf(m, src[y * side + xx]);
+        tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / side, x = i - y * side;
+        float m = -INFINITY;
+        const int lo = max(0, y - r), hi = min(side - 1, y + r);
+        for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, tmp[yy * side + x]);
+        dst[i] = m;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int h, int w, int r) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    NmsSmem& sm = *reinterpret_cast<NmsSmem*>(raw);
+    const int side = NMS_T + 10 * r;
+    const int halo = 5 * r;
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * NMS_T - halo, x0 = blockIdx.x * NMS_T - halo;
+    const float* img = score + (size_t)b * h * w;
+    const int n = side * side;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ly = i / side, lx = i - ly * side;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const bool in = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+        sm.inside[i] = in;
+        sm.s[i] = in ? img[(size_t)gy * w + gx] : -INFINITY;
+    }
+    __syncthreads();
+    nms_pool(sm.s, sm.t, sm.p, side, r);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sm.mask[i] = sm.inside[i] && (sm.s[i] == sm.p[i]);
+    __syncthreads();
+    for (int round = 0; round < 2; ++round) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) sm.x[i] = sm.inside[i] ? (sm.mask[i] ? 1.f : 0.f) : -INFINITY;
+        __syncthreads();
+        nms_pool(sm.x, sm.t, sm.p, side, r);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const bool sp = sm.p[i] > 0.f;
+            sm.supp[i] = sp;
+            sm.x[i] = sm.inside[i] ? (sp ? 0.f : sm.s[i]) : -INFINITY;
+        }
+        __syncthreads();
+        nms_pool(sm.x, sm.t, sm.p, side, r);
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (sm.inside[i] && (sm.x[i] == sm.p[i]) && !sm.supp[i]) sm.mask[i] = 1;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NMS_T * NMS_T; i += blockDim.x) {
+        const int ty = i / NMS_T, tx = i - ty * NMS_T;
+        const int gy = blockIdx.y * NMS_T + ty, gx = blockIdx.x * NMS_T + tx;
+        if (gy < h && gx < w) {
+            const int li = (ty + halo) * side + tx + halo;
+            out[((size_t)b * h + gy) * w + gx] = sm.mask[li] ? sm.s[li] : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K4: keypoint selection
+constexpr int SEL_T = 1024;       // threads per image
+constexpr int SEL_KMAX = 8192;    // max_keypoints supported by the in-LDS sort
+
+struct SelWs {
+    int* cnt_hi;            // [batch]   #(nms >= conf_th), no border test  (fallback decision)
+    unsigned* cand;         // [batch][h*w]  flat indices of candidates, row-major order
+};
+
+__global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict__ nms, int hw, float th, int* __restrict__ cnt) {
+    const int b = blockIdx.y;
+    const float* img = nms + (size_t)b * hw;
+    int c = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) c += img[i] >= th;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[b], c);
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns the exclusive
+// prefix and writes the block total to *total.  Uses sbuf[17].
+__device__ __forceinline__ int block_excl_scan(int v, int* sbuf, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sbuf[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < SEL_T / 64; ++i) { const int t = sbuf[i]; sbuf[i] = run; run += t; }
+        sbuf[16] = run;
+    }
+    __syncthreads();
+    const int res = sbuf[wave] + inc - v;
+    *total = sbuf[16];
+    __syncthreads();
+    return res;
+}
+
+__global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restrict__ nms, int h, int w, float conf_th,
+                                                           int min_kp, int border, int kmax, int fallback_ref, SelWs ws,
+                                                           float* __restrict__ kpts, float* __restrict__ scores,
+                                                           int* __restrict__ counts) {
+    __shared__ unsigned long long keys[SEL_KMAX];
+    __shared__ int hist[256];
+    __shared__ int sbuf[17];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_remaining;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int hw = h * w;
+    const float* img = nms + (size_t)b * hw;
+    unsigned* cand = ws.cand + (size_t)b * hw;
+    const int ref = fallback_ref < 0 ? b : fallback_ref;
+    const float th = (ws.cnt_hi[ref] <= min_kp) ? conf_th * 0.5f : conf_th;
+
+    // ---- pass 1: ordered compaction of the candidates (>= th, inside the border)
+    int c = 0;
+    for (int base = 0; base < hw; base += SEL_T) {
+        const int i = base + tid;
+        bool keep = false;
+        if (i < hw) {
+            const int y = i / w, x = i - y * w;
+            keep = img[i] >= th && y >= border && y < h - border && x >= border && x < w - border;
+        }
+        int tot;
+        const int pos = block_excl_scan(keep ? 1 : 0, sbuf, &tot);
+        if (keep) cand[c + pos] = (unsigned)i;
+        c += tot;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    float* ko = kpts + (size_t)b * kmax * 2;
+    float* so = scores + (size_t)b * kmax;
+    if (c <= kmax) {   // fewer than k: keep the row-major nonzero() order (top_k_keypoints, sfd2.py:47-48)
+        for (int i = tid; i < c; i += SEL_T) {
+            const unsigned idx = cand[i];
+            ko[2 * i] = (float)(idx % w);
+            ko[2 * i + 1] = (float)(idx / w);
+            so[i] = img[idx];
+        }
+        if (tid == 0) counts[b] = c;
+        return;
+    }
+
+    // ---- radix select of the k-th largest score (positive floats: bit pattern is monotone)
+    if (tid == 0) { s_prefix = 0u; s_remaining = kmax; }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < c; i += SEL_T) {
+            const unsigned bits = __float_as_uint(img[cand[i]]);
+            if ((bits & himask) == prefix) atomicAdd(&hist[(bits >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = s_remaining;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (hist[d] >= rem) break;
+                rem -= hist[d];
+            }
+            s_remaining = rem;
+            s_prefix = prefix | ((unsigned)d << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned tbits = s_prefix;      // bit pattern of the k-th largest score
+    const int take_eq = s_remaining;      // how many candidates equal to it are taken (lowest index first)
+
+    // ---- pass 2: ordered gather of the selected k into LDS keys
+    int ngt = 0, neq = 0;
+    for (int base = 0; base < c; base += SEL_T) {
+        const int i = base + tid;
+        unsigned idx = 0, bits = 0;
+        bool gt = false, eq = false;
+        if (i < c) {
+            idx = cand[i];
+            bits = __float_as_uint(img[idx]);
+            gt = bits > tbits;
+            eq = bits == tbits;
+        }
+        int tot_eq, tot_gt;
+        const int peq = block_excl_scan(eq ? 1 : 0, sbuf, &tot_eq);
+        const int pgt = block_excl_scan(gt ? 1 : 0, sbuf, &tot_gt);
+        const bool sel = gt || (eq && (neq + peq) < take_eq);
+        // slot: order within the selected set does not matter before the sort; use (#gt so far) + (#eq taken so far)
+        if (sel) {
+            const int eq_before = min(neq + peq, take_eq);
+            const int slot = ngt + pgt + eq_before;
+            keys[slot] = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+        }
+        ngt += tot_gt;
+        neq += tot_eq;
+    }
+    int p2 = 1;
+    while (p2 < kmax) p2 <<= 1;
+    for (int i = kmax + tid; i < p2; i += SEL_T) keys[i] = 0ull;
+    __syncthreads();
+    // ---- bitonic sort, descending: (score desc, flat index asc)
+    for (int k2 = 2; k2 <= p2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < p2; i += SEL_T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], bb = keys[ixj];
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? (a < bb) : (a > bb)) { keys[i] = bb; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < kmax; i += SEL_T) {
+        const unsigned long long kk = keys[i];
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull);
+        ko[2 * i] = (float)(idx % w);
+        ko[2 * i + 1] = (float)(idx / w);
+        so[i] = __uint_as_float((unsigned)(kk >> 32));
+    }
+    if (tid == 0) counts[b] = kmax;
+}
+
+// ---------------------------------------------------------------- K5: bilinear sampling of an NHWC map
+// one wave per keypoint; grid_sample(bilinear, align_corners=True, zeros padding) arithmetic.
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ fmap, int fh, int fw, int c,
+                                                     const float* __restrict__ kpts, const int* __restrict__ lens,
+                                                     int n_max, float s, int l2norm, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int len = lens ? lens[b] : n_max;
+    if (n >= len) return;
+    const float kx = kpts[((size_t)b * n_max + n) * 2], ky = kpts[((size_t)b * n_max + n) * 2 + 1];
+    // sample_descriptors: k = k - s/2 + 0.5 ; k /= (w*s - s/2 - 0.5, h*s - s/2 - 0.5) ; k = k*2 - 1
+    const float half = s * 0.5f;
+    const float dx = (float)fw * s - half - 0.5f, dy = (float)fh * s - half - 0.5f;
+    float gx = (kx - half) + 0.5f;
+    float gy = (ky - half) + 0.5f;
+    gx = gx / dx;
+    gy = gy / dy;
+    gx = gx * 2.f - 1.f;
+    gy = gy * 2.f - 1.f;
+    // grid_sampler_compute_source_index, align_corners=True: ((g + 1) / 2) * (size - 1)
+    const float ix = ((gx + 1.f) / 2.f) * (float)(fw - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(fh - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wnw = ((fx0 + 1.f) - ix) * ((fy0 + 1.f) - iy);
+    const float wne = (ix - fx0) * ((fy0 + 1.f) - iy);
+    const float wsw = ((fx0 + 1.f) - ix) * (iy - fy0);
+    const float wse = (ix - fx0) * (iy - fy0);
+    const bool vx0 = (unsigned)x0 < (unsigned)fw, vx1 = (unsigned)x1 < (unsigned)fw;
+    const bool vy0 = (unsigned)y0 < (unsigned)fh, vy1 = (unsigned)y1 < (unsigned)fh;
+    const float* base = fmap + (size_t)b * fh * fw * c;
+    float* dst = out + ((size_t)b * n_max + n) * c;
+    // up to two float4 per lane (c <= 512), named registers (no runtime-indexed arrays)
+    auto gather = [&](int c4) -> float4 {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 * 4 < c) {
+            auto tap = [&](bool ok, int yy, int xx, float wgt) {
+                if (ok) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)yy * fw + xx) * c + c4 * 4);
+                    a.x += v.x * wgt; a.y += v.y * wgt; a.z += v.z * wgt; a.w += v.w * wgt;
+                }
+            };
+            tap(vx0 && vy0, y0, x0, wnw);
+            tap(vx1 && vy0, y0, x1, wne);
+            tap(vx0 && vy1, y1, x0, wsw);
+            tap(vx1 && vy1, y1, x1, wse);
+        }
+        return a;
+    };
+    float4 a0 = gather(lane), a1 = gather(lane + 64);
+    if (l2norm) {
+        const float sq = ((a0.x * a0.x + a0.y * a0.y) + (a0.z * a0.z + a0.w * a0.w)) +
+                         ((a1.x * a1.x + a1.y * a1.y) + (a1.z * a1.z + a1.w * a1.w));
+        const float d = fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
+        a0.x /= d; a0.y /= d; a0.z /= d; a0.w /= d;
+        a1.x /= d; a1.y /= d; a1.z /= d; a1.w /= d;
+    }
+    if (lane * 4 < c) *reinterpret_cast<float4*>(dst + lane * 4) = a0;
+    if ((lane + 64) * 4 < c) *reinterpret_cast<float4*>(dst + (lane + 64) * 4) = a1;
+}
+
+// F.normalize over the channel (last NHWC) dim, in place: x / max(||x||, 1e-12)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = x + (size_t)row * cols;
+    float sq = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const float d = fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
+    for (int c = lane * 4; c < cols; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p + c);
+        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        *reinterpret_cast<float4*>(p + c) = v;
+    }
+}
+
+__global__ void score_lookup_kernel(const float* __restrict__ sm, long long map_stride, int h, int w,
+                                    const float* __restrict__ kpts, const int* __restrict__ lens, int n_max,
+                                    float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int len = lens ? lens[b] : n_max;
+    if (n >= len) return;
+    const long long x = (long long)kpts[((size_t)b * n_max + n) * 2];       // .long() truncation
+    const long long y = (long long)kpts[((size_t)b * n_max + n) * 2 + 1];
+    out[(size_t)b * n_max + n] = sm[b * map_stride + y * w + x];
+}
+
+}  // namespace
+
+extern "C" int pram_score_map_f32(const float* logits, float* score, int batch, int hc, int wc, void* stream) {
+    PRAM_REQUIRE(logits && score, "pram_score_map_f32: null pointer");
+    const int ncell = batch * hc * wc;
+    if (ncell == 0) return PRAM_OK;
+    hipLaunchKernelGGL(score_map_kernel, dim3(cdiv(ncell, 4)), dim3(256), 0, (hipStream_t)stream, logits, score, hc, wc, ncell);
+    return pram_launch_status("pram_score_map_f32");
+}
+
+extern "C" int pram_simple_nms_f32(const float* score, float* nms, int batch, int h, int w, int radius, void* stream) {
+    PRAM_REQUIRE(score && nms, "pram_simple_nms_f32: null pointer");
+    PRAM_REQUIRE(radius >= 0 && radius <= NMS_RMAX, "pram_simple_nms_f32: radius %d > %d", radius, NMS_RMAX);
+    if (batch == 0) return PRAM_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsSmem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(cdiv(w, NMS_T), cdiv(h, NMS_T), batch), dim3(256), sizeof(NmsSmem), (hipStream_t)stream,
+                       score, nms, h, w, radius);
+    return pram_launch_status("pram_simple_nms_f32");
+}
+
+static SelWs sel_carve(void* ws, int batch, int h, int w, size_t* total) {
+    SelWs s;
+    char* base = (char*)ws;
+    size_t off = 0;
+    s.cnt_hi = (int*)(base + off);
+    off += ((size_t)batch * 4 + 255) & ~(size_t)255;
+    s.cand = (unsigned*)(base + off);
+    off += ((size_t)batch * h * w * 4 + 255) & ~(size_t)255;
+    if (total) *total = off;
+    return s;
+}
+
+extern "C" size_t pram_select_keypoints_workspace_bytes(int batch, int h, int w, int max_keypoints) {
+    size_t total = 0;
+    sel_carve(nullptr, batch, h, w, &total);
+    (void)max_keypoints;
+    return total;
+}
+
+extern "C" int pram_select_keypoints_f32(const float* nms, int batch, int h, int w, float conf_th, int min_keypoints,
+                                         int border, int max_keypoints, int fallback_ref, float* kpts, float* scores,
+                                         int* counts, void* workspace, void* stream) {
+    PRAM_REQUIRE(nms && kpts && scores && counts && workspace, "pram_select_keypoints_f32: null pointer");
+    PRAM_REQUIRE(max_keypoints > 0 && max_keypoints <= SEL_KMAX, "pram_select_keypoints_f32: max_keypoints=%d not in (0, %d]",
+                 max_keypoints, SEL_KMAX);
+    PRAM_REQUIRE(fallback_ref < batch, "pram_select_keypoints_f32: fallback_ref out of range");
+    PRAM_REQUIRE(conf_th > 0.f, "pram_select_keypoints_f32: conf_th must be positive");
+    if (batch == 0) return PRAM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SelWs ws = sel_carve(workspace, batch, h, w, nullptr);
+    if (hipMemsetAsync(ws.cnt_hi, 0, (size_t)batch * 4, st) != hipSuccess) {
+        pram_set_error("pram_select_keypoints_f32: memset failed");
+        return PRAM_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(sel_count_kernel, dim3(64, batch), dim3(256), 0, st, nms, h * w, conf_th, ws.cnt_hi);
+    hipLaunchKernelGGL(sel_select_kernel, dim3(batch), dim3(SEL_T), 0, st, nms, h, w, conf_th, min_keypoints, border,
+                       max_keypoints, fallback_ref, ws, kpts, scores, counts);
+    return pram_launch_status("pram_select_keypoints_f32");
+}
+
+extern "C" int pram_sample_nhwc_f32(const float* fmap, int batch, int fh, int fw, int c, const float* kpts, const int* lens,
+                                    int n_max, int s, int l2norm, float* out, void* stream) {
+    PRAM_REQUIRE(fmap && kpts && out, "pram_sample_nhwc_f32: null pointer");
+    PRAM_REQUIRE(c % 4 == 0 && c <= 512, "pram_sample_nhwc_f32: c=%d must be a multiple of 4 and <= 512", c);
+    if (batch == 0 || n_max == 0) return PRAM_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(n_max, 4), batch), dim3(256), 0, (hipStream_t)stream, fmap, fh, fw, c, kpts,
+                       lens, n_max, (float)s, l2norm, out);
+    return pram_launch_status("pram_sample_nhwc_f32");
+}
+
+extern "C" int pram_l2norm_rows_f32(float* x, int rows, int cols, void* stream) {
+    PRAM_REQUIRE(x && cols % 4 == 0, "pram_l2norm_rows_f32: cols must be a multiple of 4");
+    if (rows == 0) return PRAM_OK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, cols);
+    return pram_launch_status("pram_l2norm_rows_f32");
+}
+
+extern "C" int pram_score_lookup_f32(const float* score_map, long long map_stride, int h, int w, const float* kpts,
+                                     const int* lens, int batch, int n_max, float* out, void* stream) {
+    PRAM_REQUIRE(score_map && kpts && out, "pram_score_lookup_f32: null pointer");
+    if (batch == 0 || n_max == 0) return PRAM_OK;
+    hipLaunchKernelGGL(score_lookup_kernel, dim3(cdiv(n_max, 256), batch), dim3(256), 0, (hipStream_t)stream, score_map,
+                       map_stride, h, w, kpts, lens, n_max, out);
+    return pram_launch_status("pram_score_lookup_f32");
+}

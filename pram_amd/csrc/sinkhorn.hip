@@ -1,0 +1,431 @@
+// Plain-domain Sinkhorn on the dustbin-augmented score matrix + mutual-NN match extraction.
+// Reference: sink_algorithm / sinkhorn nets/gml.py:27-46, dual_softmax :20-24,
+// compute_matches :304-319 (identical copies in nets/gm.py and nets/adagml.py).
+//
+// HBM/L2-bound.  The reference streams the (m+1)x(n+1) matrix ~44 times (softmax, 2 x 20
+// masked reductions with temporaries, final scaling).  Here each Sinkhorn iteration reads P
+// ONCE: a wave owns a row, keeps it in registers, forms u_i = r_i / (P_i·v + eps) with a wave
+// reduction and immediately accumulates P_ij * u_i into per-lane column accumulators; the
+// per-wave column partials are summed by a small second kernel that also forms v.  Row blocks
+// are contiguous per workgroup, so with the XCD round-robin each XCD keeps re-reading the same
+// 1/8 of P from its own L2 across iterations (16.8 MB at 2049^2 -> 2.1 MB per 4-MiB L2).
+// compute_matches is fused into the final pass (row max/argmax by wave reduction, column
+// max/argmax by the same partial scheme); argmax ties resolve to the lowest index like
+// torch.max(dim).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float SINK_EPS = 1e-8f;  // nets/gml.py:17
+constexpr int NBLK = 32;           // row blocks per batch element -> 128 waves, 128 column partials
+
+struct SinkWs {
+    float* P;       // [batch][m_max+1][ldw]
+    float* u;       // [batch][m_max+1]
+    float* v;       // [batch][ldw]
+    float* part;    // [batch][NBLK*4][ldw]   column partial sums / partial max values
+    int* parti;     // [batch][NBLK*4][ldw]   column partial argmax
+    float* rowval;  // [batch][m_max]
+    int* rowidx;    // [batch][m_max]
+    float* colval;  // [batch][n_max]
+    int* colidx;    // [batch][n_max]
+    float* rlse;    // [batch][m_max+1]  (dual-softmax only)
+    float* clse;    // [batch][ldw]
+    int ldw;
+};
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static SinkWs carve(void* ws, int batch, int m_max, int n_max, size_t* total) {
+    SinkWs w;
+    w.ldw = ((n_max + 1 + 3) / 4) * 4;
+    size_t off = 0;
+    char* base = (char*)ws;
+    auto take = [&](size_t bytes) { char* p = base + off; off += align256(bytes); return p; };
+    w.P = (float*)take((size_t)batch * (m_max + 1) * w.ldw * 4);
+    w.u = (float*)take((size_t)batch * (m_max + 1) * 4);
+    w.v = (float*)take((size_t)batch * w.ldw * 4);
+    w.part = (float*)take((size_t)batch * NBLK * 4 * w.ldw * 4);
+    w.parti = (int*)take((size_t)batch * NBLK * 4 * w.ldw * 4);
+    w.rowval = (float*)take((size_t)batch * m_max * 4);
+    w.rowidx = (int*)take((size_t)batch * m_max * 4);
+    w.colval = (float*)take((size_t)batch * n_max * 4);
+    w.colidx = (int*)take((size_t)batch * n_max * 4);
+    w.rlse = (float*)take((size_t)batch * (m_max + 1) * 4);
+    w.clse = (float*)take((size_t)batch * w.ldw * 4);
+    if (total) *total = off;
+    return w;
+}
+
+// ---- row softmax of the augmented matrix (one wave per row), v <- 1 ---------------------------
+// mode 0: write softmax probabilities (Sinkhorn);  mode 1: write raw augmented scores and the row
+// log-sum-exp (dual softmax).
+__global__ __launch_bounds__(256) void sink_init_kernel(const float* __restrict__ dist, int ldd, long long sdist,
+                                                        const int* __restrict__ m_lens, const int* __restrict__ n_lens,
+                                                        const float* __restrict__ bin, SinkWs w, int m_max, int n_max,
+                                                        int mode) {
+    const int b = blockIdx.y;
+    const int m = m_lens ? m_lens[b] : m_max, n = n_lens ? n_lens[b] : n_max;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i == 0)
+        for (int j = lane; j < w.ldw; j += 64) w.v[(size_t)b * w.ldw + j] = 1.0f;
+    if (i > m) return;
+    const float bs = bin[0];
+    const float* src = dist + b * sdist + (size_t)i * ldd;
+    float* dst = w.P + ((size_t)b * (m_max + 1) + i) * w.ldw;
+    const bool binrow = (i == m);
+    float mx = bs;
+    if (!binrow)
+        for (int j = lane; j < n; j += 64) mx = fmaxf(mx, src[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= n; j += 64) {
+        const float x = (binrow || j == n) ? bs : src[j];
+        sum += expf(x - mx);
+    }
+    sum = wave_sum(sum);
+    if (mode == 0) {
+        for (int j = lane; j < w.ldw; j += 64) {
+            float pv = 0.f;
+            if (j <= n) {
+                const float x = (binrow || j == n) ? bs : src[j];
+                pv = expf(x - mx) / sum;
+            }
+            dst[j] = pv;
+        }
+    } else {
+        for (int j = lane; j < w.ldw; j += 64) dst[j] = (j <= n) ? ((binrow || j == n) ? bs : src[j]) : -INFINITY;
+        if (lane == 0) w.rlse[(size_t)b * (m_max + 1) + i] = mx + logf(sum);
+    }
+}
+
+// ---- one Sinkhorn iteration: u = r / (P v + eps), column partials of P^T u -----------------------
+template <int NV>
+__global__ __launch_bounds__(256) void sink_iter_kernel(const int* __restrict__ m_lens, const int* __restrict__ n_lens,
+                                                        SinkWs w, int m_max, int n_max) {
+    extern __shared__ __attribute__((aligned(16))) float sv[];
+    const int b = blockIdx.y;
+    const int m = m_lens ? m_lens[b] : m_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ldw = w.ldw;
+    for (int j = tid; j < ldw; j += 256) sv[j] = w.v[(size_t)b * ldw + j];
+    __syncthreads();
+    const int rows = m + 1;
+    const int rpb = (rows + NBLK - 1) / NBLK;
+    const int rbeg = blockIdx.x * rpb;
+    const int rend = min(rows, rbeg + rpb);
+    float4 cacc[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) cacc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Pb = w.P + (size_t)b * (m_max + 1) * ldw;
+    for (int i = rbeg + wave; i < rend; i += 4) {
+        float4 pr[NV];
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int c = (t * 64 + lane) * 4;
+            if (c < ldw) {
+                pr[t] = *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c);
+                const float4 vv = *reinterpret_cast<const float4*>(sv + c);
+                dot += (pr[t].x * vv.x + pr[t].y * vv.y) + (pr[t].z * vv.z + pr[t].w * vv.w);
+            } else {
+                pr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        dot = wave_sum(dot);
+        const float ri = (i == m) ? (float)(m + 1) : 1.0f;
+        const float ui = ri / (dot + SINK_EPS);
+        if (lane == 0) w.u[(size_t)b * (m_max + 1) + i] = ui;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            cacc[t].x += pr[t].x * ui;
+            cacc[t].y += pr[t].y * ui;
+            cacc[t].z += pr[t].z * ui;
+            cacc[t].w += pr[t].w * ui;
+        }
+    }
+    float* part = w.part + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int c = (t * 64 + lane) * 4;
+        if (c < ldw) *reinterpret_cast<float4*>(part + c) = cacc[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void sink_colreduce_kernel(const int* __restrict__ n_lens, SinkWs w, int n_max) {
+    const int b = blockIdx.y;
+    const int n = n_lens ? n_lens[b] : n_max;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= w.ldw) return;
+    const float* part = w.part + (size_t)b * NBLK * 4 * w.ldw + j;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < NBLK * 4; ++k) s += part[(size_t)k * w.ldw];
+    const float cj = (j == n) ? (float)(n + 1) : 1.0f;
+    w.v[(size_t)b * w.ldw + j] = (j <= n) ? cj / (s + SINK_EPS) : 0.f;
+}
+
+// ---- final pass: p = P*u*v (or the dual-softmax score), row max/argmax, column partial max ----------
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void sink_final_kernel(const int* __restrict__ m_lens, const int* __restrict__ n_lens,
+                                                         SinkWs w, int m_max, int n_max, float* __restrict__ p_out,
+                                                         int ldp) {
+    extern __shared__ __attribute__((aligned(16))) float sv[];
+    const int b = blockIdx.y;
+    const int m = m_lens ? m_lens[b] : m_max, n = n_lens ? n_lens[b] : n_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ldw = w.ldw;
+    const float* colvec = (MODE == 0) ? w.v : w.clse;
+    for (int j = tid; j < ldw; j += 256) sv[j] = colvec[(size_t)b * ldw + j];
+    __syncthreads();
+    const int rows = m + 1;
+    const int rpb = (rows + NBLK - 1) / NBLK;
+    const int rbeg = blockIdx.x * rpb;
+    const int rend = min(rows, rbeg + rpb);
+    float cmax[NV * 4];
+    int cidx[NV * 4];
+#pragma unroll
+    for (int t = 0; t < NV * 4; ++t) { cmax[t] = -INFINITY; cidx[t] = 0x7fffffff; }
+    const float* Pb = w.P + (size_t)b * (m_max + 1) * ldw;
+    const float* rowvec = (MODE == 0) ? w.u : w.rlse;
+    for (int i = rbeg + wave; i < rend; i += 4) {
+        const float ui = rowvec[(size_t)b * (m_max + 1) + i];
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int c = (t * 64 + lane) * 4;
+            if (c < ldw) {
+                const float4 pr = *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c);
+                const float4 vv = *reinterpret_cast<const float4*>(sv + c);
+                float pv[4];
+                if (MODE == 0) {
+                    pv[0] = (pr.x * ui) * vv.x; pv[1] = (pr.y * ui) * vv.y;
+                    pv[2] = (pr.z * ui) * vv.z; pv[3] = (pr.w * ui) * vv.w;
+                } else {  // exp(log_softmax_row + log_softmax_col)
+                    pv[0] = expf((pr.x - ui) + (pr.x - vv.x)); pv[1] = expf((pr.y - ui) + (pr.y - vv.y));
+                    pv[2] = expf((pr.z - ui) + (pr.z - vv.z)); pv[3] = expf((pr.w - ui) + (pr.w - vv.w));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = c + k;
+                    if (p_out && j <= n) p_out[((size_t)b * (m_max + 1) + i) * ldp + j] = pv[k];
+                    if (i < m && j < n) {
+                        if (pv[k] > best) { best = pv[k]; bidx = j; }
+                        if (pv[k] > cmax[t * 4 + k]) { cmax[t * 4 + k] = pv[k]; cidx[t * 4 + k] = i; }
+                    }
+                }
+            }
+        }
+        if (i < m) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bidx, o, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (lane == 0) {
+                w.rowval[(size_t)b * m_max + i] = best;
+                w.rowidx[(size_t)b * m_max + i] = bidx;
+            }
+        }
+    }
+    float* part = w.part + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
+    int* parti = w.parti + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int c = (t * 64 + lane) * 4;
+        if (c < ldw) {
+            *reinterpret_cast<float4*>(part + c) = make_float4(cmax[t * 4], cmax[t * 4 + 1], cmax[t * 4 + 2], cmax[t * 4 + 3]);
+            *reinterpret_cast<int4*>(parti + c) = make_int4(cidx[t * 4], cidx[t * 4 + 1], cidx[t * 4 + 2], cidx[t * 4 + 3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sink_colmax_kernel(const int* __restrict__ n_lens, SinkWs w, int n_max) {
+    const int b = blockIdx.y;
+    const int n = n_lens ? n_lens[b] : n_max;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float* part = w.part + (size_t)b * NBLK * 4 * w.ldw + j;
+    const int* parti = w.parti + (size_t)b * NBLK * 4 * w.ldw + j;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int k = 0; k < NBLK * 4; ++k) {
+        const float v = part[(size_t)k * w.ldw];
+        const int i = parti[(size_t)k * w.ldw];
+        if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+    }
+    w.colval[(size_t)b * n_max + j] = best;
+    w.colidx[(size_t)b * n_max + j] = bidx;
+}
+
+// ---- mutual check + threshold (compute_matches) ------------------------------------------------------
+__global__ __launch_bounds__(256) void sink_mutual_kernel(const int* __restrict__ m_lens, const int* __restrict__ n_lens,
+                                                          SinkWs w, int m_max, int n_max, float thr,
+                                                          long long* __restrict__ matches0, long long* __restrict__ matches1,
+                                                          float* __restrict__ ms0, float* __restrict__ ms1) {
+    const int b = blockIdx.y;
+    const int m = m_lens ? m_lens[b] : m_max, n = n_lens ? n_lens[b] : n_max;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const float* rowval = w.rowval + (size_t)b * m_max;
+    const int* rowidx = w.rowidx + (size_t)b * m_max;
+    const int* colidx = w.colidx + (size_t)b * n_max;
+    if (t < m_max) {
+        long long mi = -1;
+        float sc = 0.f;
+        if (t < m && n > 0) {
+            const int j = rowidx[t];
+            const bool mutual = colidx[j] == t;
+            sc = mutual ? rowval[t] : 0.f;
+            if (mutual && sc > thr) mi = j;
+        }
+        if (matches0) matches0[(size_t)b * m_max + t] = mi;
+        if (ms0) ms0[(size_t)b * m_max + t] = sc;
+    }
+    if (t < n_max) {
+        long long mj = -1;
+        float sc = 0.f;
+        if (t < n && m > 0) {
+            const int i = colidx[t];
+            const bool mutual1 = rowidx[i] == t;
+            const bool mutual0 = colidx[rowidx[i]] == i;
+            const float s0 = mutual0 ? rowval[i] : 0.f;
+            sc = mutual1 ? s0 : 0.f;
+            if (mutual1 && mutual0 && s0 > thr) mj = i;
+        }
+        if (matches1) matches1[(size_t)b * n_max + t] = mj;
+        if (ms1) ms1[(size_t)b * n_max + t] = sc;
+    }
+}
+
+// ---- dual softmax: column log-sum-exp of the augmented matrix (partials per wave, then combine) -----
+template <int NV>
+__global__ __launch_bounds__(256) void dual_colpart_kernel(const int* __restrict__ m_lens, SinkWs w, int m_max) {
+    const int b = blockIdx.y;
+    const int m = m_lens ? m_lens[b] : m_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ldw = w.ldw;
+    const int rows = m + 1;
+    const int rpb = (rows + NBLK - 1) / NBLK;
+    const int rbeg = blockIdx.x * rpb;
+    const int rend = min(rows, rbeg + rpb);
+    float cm[NV * 4], cs[NV * 4];
+#pragma unroll
+    for (int t = 0; t < NV * 4; ++t) { cm[t] = -INFINITY; cs[t] = 0.f; }
+    const float* Pb = w.P + (size_t)b * (m_max + 1) * ldw;
+    for (int i = rbeg + wave; i < rend; i += 4) {
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int c = (t * 64 + lane) * 4;
+            if (c < ldw) {
+                const float4 pr = *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c);
+                const float x[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float nm = fmaxf(cm[t * 4 + k], x[k]);
+                    if (nm > -INFINITY) {
+                        cs[t * 4 + k] = cs[t * 4 + k] * expf(cm[t * 4 + k] - nm) + expf(x[k] - nm);
+                        cm[t * 4 + k] = nm;
+                    }
+                }
+            }
+        }
+    }
+    float* part = w.part + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
+    float* parts = reinterpret_cast<float*>(w.parti) + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int c = (t * 64 + lane) * 4;
+        if (c < ldw) {
+            *reinterpret_cast<float4*>(part + c) = make_float4(cm[t * 4], cm[t * 4 + 1], cm[t * 4 + 2], cm[t * 4 + 3]);
+            *reinterpret_cast<float4*>(parts + c) = make_float4(cs[t * 4], cs[t * 4 + 1], cs[t * 4 + 2], cs[t * 4 + 3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dual_colreduce_kernel(SinkWs w) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= w.ldw) return;
+    const float* part = w.part + (size_t)b * NBLK * 4 * w.ldw + j;
+    const float* parts = reinterpret_cast<const float*>(w.parti) + (size_t)b * NBLK * 4 * w.ldw + j;
+    float mx = -INFINITY;
+    for (int k = 0; k < NBLK * 4; ++k) mx = fmaxf(mx, part[(size_t)k * w.ldw]);
+    float s = 0.f;
+    if (mx > -INFINITY)
+        for (int k = 0; k < NBLK * 4; ++k) {
+            const float pm = part[(size_t)k * w.ldw];
+            if (pm > -INFINITY) s += parts[(size_t)k * w.ldw] * expf(pm - mx);
+        }
+    w.clse[(size_t)b * w.ldw + j] = (mx > -INFINITY) ? mx + logf(s) : INFINITY;
+}
+
+template <int NV>
+int run_sinkhorn(const float* dist, int ldd, const int* m_lens, const int* n_lens, const float* bin, int iters,
+                 float thr, float* p_out, int ldp, long long* matches0, long long* matches1, float* ms0, float* ms1,
+                 int batch, int m_max, int n_max, SinkWs w, hipStream_t st, bool dual) {
+    const size_t shm = (size_t)w.ldw * 4;
+    dim3 grow(cdiv(m_max + 1, 4), batch), giter(NBLK, batch), gcol(cdiv(w.ldw, 256), batch);
+    hipLaunchKernelGGL(sink_init_kernel, grow, dim3(256), 0, st, dist, ldd, (long long)m_max * ldd, m_lens, n_lens, bin,
+                       w, m_max, n_max, dual ? 1 : 0);
+    if (!dual) {
+        for (int it = 0; it < iters; ++it) {
+            hipLaunchKernelGGL(sink_iter_kernel<NV>, giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max);
+            hipLaunchKernelGGL(sink_colreduce_kernel, gcol, dim3(256), 0, st, n_lens, w, n_max);
+        }
+        hipLaunchKernelGGL((sink_final_kernel<NV, 0>), giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
+    } else {
+        hipLaunchKernelGGL(dual_colpart_kernel<NV>, giter, dim3(256), 0, st, m_lens, w, m_max);
+        hipLaunchKernelGGL(dual_colreduce_kernel, gcol, dim3(256), 0, st, w);
+        hipLaunchKernelGGL((sink_final_kernel<NV, 1>), giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
+    }
+    hipLaunchKernelGGL(sink_colmax_kernel, dim3(cdiv(n_max, 256), batch), dim3(256), 0, st, n_lens, w, n_max);
+    hipLaunchKernelGGL(sink_mutual_kernel, dim3(cdiv(m_max > n_max ? m_max : n_max, 256), batch), dim3(256), 0, st, m_lens, n_lens, w,
+                       m_max, n_max, thr, matches0, matches1, ms0, ms1);
+    return pram_launch_status(dual ? "pram_dual_softmax_match_f32" : "pram_sinkhorn_match_f32");
+}
+
+int dispatch(const float* dist, int ldd, const int* m_lens, const int* n_lens, const float* bin, int iters, float thr,
+             float* p_out, int ldp, long long* matches0, long long* matches1, float* ms0, float* ms1, int batch,
+             int m_max, int n_max, void* workspace, void* stream, bool dual) {
+    PRAM_REQUIRE(dist && bin && workspace, "sinkhorn: null pointer");
+    PRAM_REQUIRE(batch >= 0 && m_max > 0 && n_max > 0 && iters >= 0, "sinkhorn: bad sizes");
+    PRAM_REQUIRE(n_max + 1 <= 17 * 256, "sinkhorn: n_max=%d exceeds 4351 columns", n_max);
+    PRAM_REQUIRE(!p_out || ldp >= n_max + 1, "sinkhorn: ldp too small");
+    if (batch == 0) return PRAM_OK;
+    SinkWs w = carve(workspace, batch, m_max, n_max, nullptr);
+    hipStream_t st = (hipStream_t)stream;
+#define RUN(NV) return run_sinkhorn<NV>(dist, ldd, m_lens, n_lens, bin, iters, thr, p_out, ldp, matches0, matches1, ms0, ms1, batch, m_max, n_max, w, st, dual)
+    if (w.ldw <= 2 * 256) RUN(2);
+    if (w.ldw <= 5 * 256) RUN(5);
+    if (w.ldw <= 9 * 256) RUN(9);
+    RUN(17);
+#undef RUN
+}
+
+}  // namespace
+
+extern "C" size_t pram_sinkhorn_workspace_bytes(int batch, int m_max, int n_max) {
+    size_t total = 0;
+    carve(nullptr, batch, m_max, n_max, &total);
+    return total;
+}
+
+extern "C" int pram_sinkhorn_match_f32(const float* dist, int ldd, const int* m_lens, const int* n_lens,
+                                       const float* bin_score, int iters, float match_threshold, float* p_out, int ldp,
+                                       long long* matches0, long long* matches1, float* mscores0, float* mscores1,
+                                       int batch, int m_max, int n_max, void* workspace, void* stream) {
+    return dispatch(dist, ldd, m_lens, n_lens, bin_score, iters, match_threshold, p_out, ldp, matches0, matches1,
+                    mscores0, mscores1, batch, m_max, n_max, workspace, stream, false);
+}
+
+extern "C" int pram_dual_softmax_match_f32(const float* dist, int ldd, const int* m_lens, const int* n_lens,
+                                           const float* bin_score, float match_threshold, float* p_out, int ldp,
+                                           long long* matches0, long long* matches1, float* mscores0, float* mscores1,
+                                           int batch, int m_max, int n_max, void* workspace, void* stream) {
+    return dispatch(dist, ldd, m_lens, n_lens, bin_score, 0, match_threshold, p_out, ldp, matches0, matches1, mscores0,
+                    mscores1, batch, m_max, n_max, workspace, stream, true);
+}

@@ -1,0 +1,141 @@
+"""Shared attention-block runners for SegNetViT / GML / AdaGML on the HIP kernels.
+
+Tokens travel as one contiguous fp32 matrix [S*T, 256] (S sequences padded to T rows) plus an
+optional int32 device array ``lens`` [S]; nothing here synchronises with the host.
+
+Weight packing (done once per device, cached by the owning module):
+  * ``qkv``: the reference views Linear(256->768) output as (head 4, dim 64, {q,k,v})
+    (nets/segnetvit.py:98-100), i.e. row c = h*192 + d*3 + s.  Rows are re-ordered to
+    [q | k | v] x [head] x [dim], and inside every q/k head the 32 even rotary dims come first,
+    then the 32 odd ones.  q·k is invariant under a common permutation of the head dim, and the
+    rotary pair (2i, 2i+1) lands in columns (i, i+32) of the same 64-wide tile, which the GEMM
+    epilogue rotates lane-locally (PRAM_LIN_ROTARY).
+  * cross attention: ``to_qk`` and ``to_v`` are stacked into one [512,256] projection; the
+    reference's two dh^-1/4 factors (nets/gml.py:174) are applied as one dh^-1/2 score scale.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+
+HEADS = 4
+DH = 64
+
+
+def _rot_perm() -> torch.Tensor:
+    d = torch.arange(DH)
+    return torch.cat([d[0::2], d[1::2]])
+
+
+def pack_self_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[str, torch.Tensor]:
+    w = sd[prefix + ".qkv.weight"].detach().float()
+    b = sd[prefix + ".qkv.bias"].detach().float()
+    hid = w.shape[0] // 3
+    w = w.view(HEADS, DH, 3, -1)
+    b = b.view(HEADS, DH, 3)
+    perm = _rot_perm()
+    wq, wk, wv = w[:, perm, 0], w[:, perm, 1], w[:, :, 2]
+    bq, bk, bv = b[:, perm, 0], b[:, perm, 1], b[:, :, 2]
+    wp = torch.cat([wq.reshape(hid, -1), wk.reshape(hid, -1), wv.reshape(hid, -1)], 0)
+    bp = torch.cat([bq.reshape(hid), bk.reshape(hid), bv.reshape(hid)], 0)
+    out = {"qkv_w": wp, "qkv_b": bp}
+    for k in ("proj.weight", "proj.bias", "mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias",
+              "mlp.3.weight", "mlp.3.bias"):
+        out[k] = sd[f"{prefix}.{k}"].detach().float()
+    return {k: v.contiguous().to(device) for k, v in out.items()}
+
+
+def pack_cross_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[str, torch.Tensor]:
+    out = {
+        "qkv_w": torch.cat([sd[prefix + ".to_qk.weight"], sd[prefix + ".to_v.weight"]], 0).detach().float(),
+        "qkv_b": torch.cat([sd[prefix + ".to_qk.bias"], sd[prefix + ".to_v.bias"]], 0).detach().float(),
+    }
+    for k in ("proj.weight", "proj.bias", "mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias",
+              "mlp.3.weight", "mlp.3.bias"):
+        out[k] = sd[f"{prefix}.{k}"].detach().float()
+    return {k: v.contiguous().to(device) for k, v in out.items()}
+
+
+def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106)"""
+    msg = ops.linear(ctx, p["proj.weight"], p["proj.bias"])
+    h = ops.linear(x, p["mlp.0.weight"], p["mlp.0.bias"], x2=msg)
+    ops.layernorm_gelu_(h, p["mlp.1.weight"], p["mlp.1.bias"])
+    return ops.linear(h, p["mlp.3.weight"], p["mlp.3.bias"], residual=x)
+
+
+def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, sin: torch.Tensor, S: int, T: int,
+               lens: Optional[torch.Tensor], want_colmean: bool = False):
+    """x [S*T, 256] -> same.  SelfMultiHeadAttention.forward (nets/segnetvit.py:97-106)."""
+    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH))
+    hid = HEADS * DH
+    q, k, v = qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:]
+    scale = DH ** -0.5
+    if want_colmean:
+        ctx, lse = ops.attention(q, k, v, S, HEADS, T, T, scale, lens, lens, want_lse=True)
+        col = ops.attention_colmean(q, k, lse, S, HEADS, T, T, scale, lens, lens)
+        return _mlp_tail(x, ctx, p), col
+    ctx = ops.attention(q, k, v, S, HEADS, T, T, scale, lens, lens)
+    return _mlp_tail(x, ctx, p)
+
+
+def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, lens: Optional[torch.Tensor],
+                want_colmean: bool = False):
+    """x [2B*T, 256]: sequences 0..B-1 are set 0, B..2B-1 set 1.  CrossMultiHeadAttention.forward
+    (nets/gml.py:164-186): m0 = softmax_row(sim) v1, m1 = softmax_row(sim^T) v0."""
+    hid = HEADS * DH
+    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"])          # [2B*T, 512] = [qk | v]
+    half = B * T
+    qk0, qk1 = qkv[:half, :hid], qkv[half:, :hid]
+    v0, v1 = qkv[:half, hid:], qkv[half:, hid:]
+    l0 = lens[:B] if lens is not None else None
+    l1 = lens[B:] if lens is not None else None
+    scale = DH ** -0.5     # (dh^-1/4)^2
+    ctx = torch.empty(2 * half, hid, device=x.device, dtype=torch.float32)
+    if want_colmean:
+        _, lse0 = ops.attention(qk0, qk1, v1, B, HEADS, T, T, scale, l0, l1, want_lse=True, out=ctx[:half])
+        _, lse1 = ops.attention(qk1, qk0, v0, B, HEADS, T, T, scale, l1, l0, want_lse=True, out=ctx[half:])
+        # attn01 column means -> per set-1 token ; attn10 column means -> per set-0 token
+        col1 = ops.attention_colmean(qk0, qk1, lse0, B, HEADS, T, T, scale, l0, l1)
+        col0 = ops.attention_colmean(qk1, qk0, lse1, B, HEADS, T, T, scale, l1, l0)
+        return _mlp_tail(x, ctx, p), col0, col1
+    ops.attention(qk0, qk1, v1, B, HEADS, T, T, scale, l0, l1, out=ctx[:half])
+    ops.attention(qk1, qk0, v0, B, HEADS, T, T, scale, l1, l0, out=ctx[half:])
+    return _mlp_tail(x, ctx, p)
+
+
+class PackedCache:
+    """Mixin: device-side packed weights, rebuilt after load_state_dict / .to() / .cuda()."""
+
+    def _packed_get(self, builder):
+        dev = next(self.parameters()).device
+        key = str(dev)
+        cache = self.__dict__.setdefault("_packed_store", {})
+        if key not in cache:
+            cache.clear()
+            with torch.no_grad():
+                cache[key] = builder(dev)
+        return cache[key]
+
+    def _packed_invalidate(self):
+        self.__dict__.setdefault("_packed_store", {}).clear()
+
+    def _apply(self, fn, *a, **k):  # .to/.cuda/.float
+        r = super()._apply(fn, *a, **k)
+        self._packed_invalidate()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._packed_invalidate()
+        return r
+
+
+def require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        from .._lib import PramHipError
+        raise PramHipError(f"{what}: tensors must live on the GPU — pram_amd has no CPU path "
+                           "(the CPU restatement under oracle/ is test infrastructure only)")

@@ -1,0 +1,149 @@
+"""AdaGML — adaptive GML (per-layer confidence pooling, token pruning, early exit) on the HIP kernels.
+
+Same config, state-dict schema and ``produce_matches`` output as the reference
+(nets/adagml.py:232-404): ``matches0`` / ``matching_scores0`` scattered back to the full query set,
+B = 1 semantics (the reference's mask indexing drops the batch dimension; a batch of pairs is run
+pair by pair).  The per-layer stop test needs one 3-int device->host read, exactly where the
+reference's Python ``if`` synchronises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from . import _blocks as blk
+from .gml import GML, normalize_inputs, sink_algorithm, dual_softmax  # noqa: F401  (API parity)
+
+
+class _Pooling(nn.Module):
+    """Parameter holder for PoolingLayer (nets/adagml.py:114-130)."""
+
+    def __init__(self, hidden_dim: int, score_dim: int = 2):
+        super().__init__()
+        self.score_enc = nn.Sequential(nn.Linear(score_dim, hidden_dim), nn.LayerNorm(hidden_dim, elementwise_affine=True),
+                                       nn.GELU(), nn.Linear(hidden_dim, hidden_dim))
+        self.proj = nn.Linear(hidden_dim, hidden_dim)
+        self.predict = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.LayerNorm(hidden_dim, elementwise_affine=True),
+                                     nn.GELU(), nn.Linear(hidden_dim, 1))
+
+
+class AdaGML(GML):
+    default_config = {
+        'descriptor_dim': 128, 'hidden_dim': 256, 'weights': 'indoor', 'keypoint_encoder': [32, 64, 128, 256],
+        'GNN_layers': ['self', 'cross'] * 9, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_pose': True,
+        'n_layers': 9, 'n_min_tokens': 256, 'with_sinkhorn': True, 'min_confidence': 0.9,
+        'classification_background_weight': 0.05, 'pretrained': True,
+    }
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.n_min_tokens = self.config['n_min_tokens']
+        self.min_confidence = self.config['min_confidence']
+        self.pooling = nn.ModuleList([_Pooling(self.config['hidden_dim'], 2) for _ in range(self.n_layers)])
+
+    def _build_packed(self, dev):
+        P = super()._build_packed(dev)
+        sd = self.state_dict()
+        f = lambda k: sd[k].detach().float().contiguous().to(dev)
+        pools = []
+        for i in range(self.n_layers):
+            p = f"pooling.{i}"
+            w0 = sd[p + ".score_enc.0.weight"].detach().float()
+            pools.append({
+                "se0_w": torch.cat([w0, w0.new_zeros(w0.shape[0], 2)], 1).contiguous().to(dev),   # K 2 -> 4 (zero pad)
+                "se0_b": f(p + ".score_enc.0.bias"), "se1_w": f(p + ".score_enc.1.weight"), "se1_b": f(p + ".score_enc.1.bias"),
+                "se3_w": f(p + ".score_enc.3.weight"), "se3_b": f(p + ".score_enc.3.bias"),
+                "proj_w": f(p + ".proj.weight"), "proj_b": f(p + ".proj.bias"),
+                "pr0_w": f(p + ".predict.0.weight"), "pr0_b": f(p + ".predict.0.bias"),
+                "pr1_w": f(p + ".predict.1.weight"), "pr1_b": f(p + ".predict.1.bias"),
+                # N 1 -> 4 rows (zero pad) keeps the logit column 16-B aligned; column 0 is the logit
+                "pr3_w": torch.cat([sd[p + ".predict.3.weight"].detach().float(),
+                                    torch.zeros(3, sd[p + ".predict.3.weight"].shape[1])], 0).contiguous().to(dev),
+                "pr3_b": torch.cat([sd[p + ".predict.3.bias"].detach().float(), torch.zeros(3)]).contiguous().to(dev),
+            })
+        P["pool"] = pools
+        return P
+
+    def forward(self, data, mode=0):
+        if not self.training:
+            if mode == 0:
+                return self.produce_matches(data=data)
+            raise NotImplementedError("AdaGML.run (training-time evaluation helper, nets/adagml.py:406-489) is outside the hot path")
+        raise NotImplementedError("training is outside the hot path")
+
+    def confidence_threshold(self, layer_index: int):
+        """nets/adagml.py:516-520"""
+        return float(np.clip(0.5 + 0.1 * np.exp(-4.0 * layer_index / self.n_layers), 0, 1))
+
+    def _pool_logit(self, pp, x, score4):
+        """PoolingLayer.forward up to the pre-sigmoid logit (nets/adagml.py:132-136)."""
+        s = ops.linear(score4, pp["se0_w"], pp["se0_b"])
+        ops.layernorm_gelu_(s, pp["se1_w"], pp["se1_b"])
+        s = ops.linear(s, pp["se3_w"], pp["se3_b"])
+        xx = ops.linear(x, pp["proj_w"], pp["proj_b"])
+        h = ops.linear(xx, pp["pr0_w"], pp["pr0_b"], x2=s)
+        ops.layernorm_gelu_(h, pp["pr1_w"], pp["pr1_b"])
+        return ops.linear(h, pp["pr3_w"], pp["pr3_b"])[:, 0].contiguous()
+
+    @torch.no_grad()
+    def produce_matches(self, data: dict, p: float = 0.2, **kwargs):
+        desc0, desc1 = data['descriptors0'], data['descriptors1']
+        blk.require_cuda(desc0, "AdaGML.produce_matches")
+        _ = data['scores0'], data['scores1']     # read like the reference (KeyError if absent), unused in compute
+        if desc0.shape[0] != 1:
+            outs = [self.produce_matches({k: (v[i:i + 1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == desc0.shape[0]
+                                              and not k.startswith('image') else v) for k, v in data.items()}, p=p)
+                    for i in range(desc0.shape[0])]
+            return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+        probes = kwargs.get('probes')
+        (k0, cx0, cy0, sc0), (k1, cx1, cy1, sc1) = normalize_inputs(data)
+        P = self._packed_get(self._build_packed)
+        m, n = desc0.shape[1], desc1.shape[1]
+        T = max(m, n)
+        dev = desc0.device
+        X = torch.zeros(2, T, desc0.shape[2], device=dev, dtype=torch.float32)
+        X[0, :m], X[1, :n] = desc0[0], desc1[0]
+        cos = torch.zeros(2, T, 32, device=dev, dtype=torch.float32)
+        sin = torch.zeros(2, T, 32, device=dev, dtype=torch.float32)
+        c0, s0 = ops.fourier_encoding(k0.float(), P["Wr"], cx0, cy0, sc0)
+        c1, s1 = ops.fourier_encoding(k1.float(), P["Wr"], cx1, cy1, sc1)
+        cos[0, :m], sin[0, :m], cos[1, :n], sin[1, :n] = c0[0], s0[0], c1[0], s1[0]
+        ind = torch.zeros(2, T, device=dev, dtype=torch.int32)
+        ind[0, :m] = torch.arange(m, device=dev, dtype=torch.int32)
+        ind[1, :n] = torch.arange(n, device=dev, dtype=torch.int32)
+        lens = torch.tensor([m, n], device=dev, dtype=torch.int32)
+        x = ops.linear(X.view(2 * T, -1), P["in_w"], P["in_b"])
+        nI = self.n_layers
+        ni = 0
+        for ni in range(nI):
+            x, col_self = blk.self_block(x, P["self"][ni], cos.view(-1, 32), sin.view(-1, 32), 2, T, lens, want_colmean=True)
+            x, col0, col1 = blk.cross_block(x, P["cross"][ni], 1, T, lens, want_colmean=True)
+            score4 = torch.zeros(2, T, 4, device=dev, dtype=torch.float32)
+            score4[:, :, 0] = col_self
+            score4[0, :, 1], score4[1, :, 1] = col0[0], col1[0]
+            logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * T, 4)).view(2, T)
+            if ni >= 1:
+                thr = self.confidence_threshold(ni)
+                x3, cos, sin, ind, lens_new, n_below, conf = ops.adagml_prune(
+                    logit, thr, self.n_min_tokens, lens, x.view(2, T, -1), cos, sin, ind, want_conf=probes is not None)
+                x = x3.view(2 * T, -1)
+                lens = lens_new
+                if probes is not None:
+                    probes[f"conf_{ni}"] = conf
+                below = int(n_below.sum().item())     # host sync: the reference's `if self.check_if_stop(...)`
+                if 1.0 - below / float(m + n) > 0.95:
+                    break
+            elif probes is not None:
+                probes[f"conf_{ni}"] = torch.sigmoid(logit)
+        d = x.shape[-1]
+        md = ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25).view(2, T, d)
+        ldc = (T + 3) // 4 * 4
+        dist = ops.bgemm_nt(md[:1], md[1:], ldc=ldc)
+        r = ops.sinkhorn_match(dist, P["bin"], self.sinkhorn_iterations, p, m_lens=lens[:1], n_lens=lens[1:],
+                               dual_softmax=not self.with_sinkhorn, n_valid=T)
+        out_m, out_s = ops.adagml_scatter(r['matches0'], r['matching_scores0'], ind[0:1], ind[1:2], lens[:1], m)
+        if probes is not None:
+            probes.update(stop_layer=ni, ind=ind, lens=lens)
+        return {'matches0': out_m, 'matching_scores0': out_s}

@@ -1,0 +1,223 @@
+"""SFD2 keypoint / descriptor extractor ("ResNet4x") on the HIP kernels.
+
+Same state-dict schema, methods and returned dicts as the reference (nets/sfd2.py:127-369,592-596).
+Feature maps live in NHWC on the device (what the implicit-GEMM convolutions and the bilinear
+gather want); the NCHW-shaped tensors the reference returns (`desc_map`, `mid_features`,
+`global_descriptors`) are zero-copy permuted views of that storage (torch channels_last).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import _blocks as blk
+
+RGB_mean = [0.485, 0.456, 0.406]
+RGB_std = [0.229, 0.224, 0.225]
+
+
+def norm_RGB(img: torch.Tensor) -> torch.Tensor:
+    """tvf.Normalize(mean, std) (nets/sfd2.py:14-17) without torchvision."""
+    mean = img.new_tensor(RGB_mean).view(-1, 1, 1)
+    std = img.new_tensor(RGB_std).view(-1, 1, 1)
+    return (img - mean) / std
+
+
+def _conv_bn(cin, cout, stride=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class _Res(nn.Module):
+    """Parameter holder for ResBlock (nets/sfd2.py:94-105): 1x1 / grouped 3x3 / 1x1, bias-free, BN each."""
+
+    def __init__(self, planes=256, groups=32):
+        super().__init__()
+        self.conv1 = nn.Conv2d(planes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes)
+
+
+def _head(stride):
+    return nn.Sequential(nn.Conv2d(256, 256, 3, stride, 1), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+                         nn.Conv2d(256, 256, 3, 1, 1))
+
+
+class ResNet4x(blk.PackedCache, nn.Module):
+    default_config = {'conf_th': 0.005, 'remove_borders': 4, 'min_keypoints': 128, 'max_keypoints': 4096}
+
+    def __init__(self, inputdim=3, outdim=128, desc_compressor=None):
+        super().__init__()
+        assert inputdim == 3 and outdim == 128 and desc_compressor is None
+        self.outdim = outdim
+        self.conv1a, self.conv1b = _conv_bn(3, 64), _conv_bn(64, 64, 2)
+        self.conv2a, self.conv2b = _conv_bn(64, 128), _conv_bn(128, 128, 2)
+        self.conv3a, self.conv3b = _conv_bn(128, 256), _conv_bn(256, 256)
+        self.conv4 = nn.Sequential(_Res(), _Res(), _Res())
+        self.convPa, self.convDa = _head(2), _head(1)
+        self.convPb = nn.Conv2d(256, 65, 1)
+        self.convDb = nn.Conv2d(256, outdim, 1)
+
+    # ------------------------------------------------------------------ packed weights
+    @staticmethod
+    def _ohwi(w: torch.Tensor, pad_to: Optional[int] = None) -> torch.Tensor:
+        w = w.detach().float().permute(0, 2, 3, 1)
+        if pad_to is not None and w.shape[-1] < pad_to:
+            w = torch.cat([w, w.new_zeros(*w.shape[:-1], pad_to - w.shape[-1])], -1)
+        return w.contiguous()
+
+    @staticmethod
+    def _bn(sd, p):
+        scale = sd[p + ".weight"].double() / torch.sqrt(sd[p + ".running_var"].double() + 1e-5)
+        shift = sd[p + ".bias"].double() - sd[p + ".running_mean"].double() * scale
+        return scale.float(), shift.float()
+
+    def _build_packed(self, dev):
+        sd = self.state_dict()
+        P: Dict[str, torch.Tensor] = {}
+        for name in ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b"):
+            P[name + ".w"] = self._ohwi(sd[name + ".0.weight"], 4 if name == "conv1a" else None)
+            P[name + ".b"] = sd[name + ".0.bias"].float()
+            P[name + ".s"], P[name + ".t"] = self._bn(sd, name + ".1")
+        for i in range(3):
+            p = f"conv4.{i}"
+            for j in (1, 2, 3):
+                P[f"{p}.w{j}"] = self._ohwi(sd[f"{p}.conv{j}.weight"])
+                P[f"{p}.s{j}"], P[f"{p}.t{j}"] = self._bn(sd, f"{p}.bn{j}")
+        for head in ("convPa", "convDa"):
+            P[head + ".w0"] = self._ohwi(sd[head + ".0.weight"])
+            P[head + ".b0"] = sd[head + ".0.bias"].float()
+            P[head + ".s0"], P[head + ".t0"] = self._bn(sd, head + ".1")
+            P[head + ".w3"] = self._ohwi(sd[head + ".3.weight"])
+            P[head + ".b3"] = sd[head + ".3.bias"].float()
+        for head in ("convPb", "convDb"):
+            P[head + ".w"] = self._ohwi(sd[head + ".weight"])
+            P[head + ".b"] = sd[head + ".bias"].float()
+        return {k: v.contiguous().to(dev) for k, v in P.items()}
+
+    # ------------------------------------------------------------------ conv stack (NHWC in/out)
+    def _backbone(self, image: torch.Tensor):
+        blk.require_cuda(image, "ResNet4x")
+        P = self._packed_get(self._build_packed)
+        x = ops.image_to_nhwc4(image.float())
+
+        def cbr(x, n, stride=1):
+            return ops.conv2d_nhwc(x, P[n + ".w"], P[n + ".b"], P[n + ".s"], P[n + ".t"], ks=3, stride=stride, relu=True)
+
+        o1b = cbr(cbr(x, "conv1a"), "conv1b", 2)
+        o2b = cbr(cbr(o1b, "conv2a"), "conv2b", 2)
+        o3b = cbr(cbr(o2b, "conv3a"), "conv3b")
+        o4 = o3b
+        for i in range(3):
+            p = f"conv4.{i}"
+            y = ops.conv2d_nhwc(o4, P[p + ".w1"], None, P[p + ".s1"], P[p + ".t1"], ks=1, relu=True)
+            y = ops.conv3x3_grouped_nhwc(y, P[p + ".w2"], P[p + ".s2"], P[p + ".t2"], groups=32, relu=True)
+            o4 = ops.conv2d_nhwc(y, P[p + ".w3"], None, P[p + ".s3"], P[p + ".t3"], residual=o4, ks=1, relu=True)
+        return P, o1b, o2b, o3b, o4
+
+    def _score_head(self, P, o4):
+        pa = ops.conv2d_nhwc(o4, P["convPa.w0"], P["convPa.b0"], P["convPa.s0"], P["convPa.t0"], ks=3, stride=2, relu=True)
+        pa = ops.conv2d_nhwc(pa, P["convPa.w3"], P["convPa.b3"], ks=3)
+        logits = ops.conv2d_nhwc(pa, P["convPb.w"], P["convPb.b"], ks=1)
+        return logits, ops.score_map(logits)
+
+    def _desc_head(self, P, o4):
+        da = ops.conv2d_nhwc(o4, P["convDa.w0"], P["convDa.b0"], P["convDa.s0"], P["convDa.t0"], ks=3, relu=True)
+        da = ops.conv2d_nhwc(da, P["convDa.w3"], P["convDa.b3"], ks=3)
+        desc = ops.conv2d_nhwc(da, P["convDb.w"], P["convDb.b"], ks=1)
+        return ops.l2norm_rows_(desc)           # F.normalize(desc, dim=1)
+
+    @staticmethod
+    def _nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+        return x_nhwc.permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def det(self, x):
+        """-> (score [B,H,W], desc [B,128,H/4,W/4]) — nets/sfd2.py:172-199"""
+        P, _, _, _, o4 = self._backbone(x)
+        _, score = self._score_head(P, o4)
+        return score, self._nchw_view(self._desc_head(P, o4))
+
+    @torch.no_grad()
+    def forward(self, batch):
+        """nets/sfd2.py:201-233"""
+        P, _, _, _, o4 = self._backbone(batch['image'])
+        logits, score = self._score_head(P, o4)
+        desc = self._nchw_view(self._desc_head(P, o4))
+        lg = self._nchw_view(logits)
+        return {'dense_features': desc, 'scores': score, 'logits': lg, 'semi_map': torch.softmax(lg, 1)[:, :-1]}
+
+    @torch.no_grad()
+    def extract_batched(self, image: torch.Tensor, config: dict, per_image_fallback: bool = True):
+        """Device-resident, sync-free form of extract_local_global for batches of independent queries:
+        padded keypoints [B,k,2], scores [B,k], descriptors [B,k,128], counts int32 [B] (device)."""
+        cfg = {**self.default_config, **config}
+        b, _, ih, iw = image.shape
+        if ih % 8 or iw % 8:
+            raise NotImplementedError("image sides must be multiples of 8 (the bilinear score resize of "
+                                      "nets/sfd2.py:301-303 is not implemented on the GPU path)")
+        P, o1b, o2b, o3b, o4 = self._backbone(image)
+        _, score = self._score_head(P, o4)
+        nms = ops.simple_nms(score, 4)
+        if cfg['max_keypoints'] < 0:
+            raise NotImplementedError("max_keypoints < 0 (keep all) is not supported; pass a bound")
+        kpts, scores, counts = ops.select_keypoints(nms, cfg['conf_th'], cfg['min_keypoints'], cfg['remove_borders'],
+                                                    cfg['max_keypoints'], -1 if per_image_fallback else 0)
+        desc_map = self._desc_head(P, o4)
+        descs = ops.sample_nhwc(desc_map, kpts, counts, 4, True)
+        return dict(score_map=score, desc_map=desc_map, mid_features=o4, global_nhwc=[o1b, o2b, o3b, o4],
+                    keypoints=kpts, scores=scores, descriptors=descs, counts=counts)
+
+    @torch.no_grad()
+    def extract_local_global(self, data, config={'conf_th': 0.005, 'remove_borders': 4, 'min_keypoints': 128,
+                                                 'max_keypoints': 4096}):
+        """nets/sfd2.py:269-346.  The min-keypoints fallback looks at batch element 0 only, like the
+        reference; selected keypoints follow the canonical (score desc, flat index asc) order."""
+        r = self.extract_batched(data['image'], config, per_image_fallback=False)
+        counts: List[int] = r['counts'].tolist()      # the one host sync (the reference syncs in nonzero())
+        return {
+            'score_map': r['score_map'],
+            'desc_map': self._nchw_view(r['desc_map']),
+            'mid_features': self._nchw_view(r['mid_features']),
+            'global_descriptors': [self._nchw_view(t) for t in r['global_nhwc']],
+            'keypoints': [r['keypoints'][i, :c] for i, c in enumerate(counts)],
+            'scores': [r['scores'][i, :c] for i, c in enumerate(counts)],
+            'descriptors': [r['descriptors'][i, :c].t() for i, c in enumerate(counts)],
+        }
+
+    @torch.no_grad()
+    def sample(self, score_map, semi_descs, kpts, s=4, norm_desc=True):
+        """nets/sfd2.py:348-369: (scores [N], descriptors [C,N]) at kpts [N,2] of a [1,C,h,w] map."""
+        blk.require_cuda(kpts, "ResNet4x.sample")
+        b, c, h, w = semi_descs.shape
+        assert b == 1, "ResNet4x.sample is a B = 1 API in the reference (score_map[0, ...])"
+        nhwc = semi_descs.permute(0, 2, 3, 1)
+        if not nhwc.is_contiguous():
+            nhwc = nhwc.contiguous()
+        k = kpts.float().reshape(1, -1, 2)
+        d = ops.sample_nhwc(nhwc.float(), k, None, s, bool(norm_desc))
+        sc = ops.score_lookup(score_map[:1].float(), k, None)
+        return sc[0], d[0].t()
+
+    @torch.no_grad()
+    def sample_batched(self, score_map, mid_nhwc, kpts, counts, s=4, norm_desc=True):
+        """Batched sample(): [B,k,C] token-major descriptors + [B,k] scores, no host sync."""
+        return ops.score_lookup(score_map, kpts, counts), ops.sample_nhwc(mid_nhwc, kpts, counts, s, bool(norm_desc))
+
+
+def load_sfd2(weight_path):
+    """nets/sfd2.py:592-596"""
+    net = ResNet4x(inputdim=3, outdim=128)
+    net.load_state_dict(torch.load(weight_path, map_location='cpu')['state_dict'], strict=True)
+    return net
+
+
+def extract_sfd2_return(*args, **kwargs):
+    raise NotImplementedError("extract_sfd2_return (offline multi-scale extraction, nets/sfd2.py:386-589) is the "
+                              "offline-mapping variant and not on the per-query path; see DESIGN.md")

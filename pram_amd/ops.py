@@ -1,0 +1,311 @@
+"""Torch-facing wrappers over the C ABI (include/pram_hip.h).  PyTorch here is plumbing only:
+device memory (torch.empty), the current HIP stream, and nothing else — every op below is a
+hand-written gfx950 kernel in pram_amd/csrc.  All tensors must be fp32 CUDA tensors."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_INT64 = torch.int64
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.PramHipError(f"{name}: expected a CUDA tensor (pram_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.PramHipError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    """(rows, ld) of a tensor viewed as a row-major matrix over its last dim."""
+    _chk(t, name)
+    if t.stride(-1) != 1:
+        raise _lib.PramHipError(f"{name}: last dim must be contiguous")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+           rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> torch.Tensor:
+    """out = alpha * ([x | x2] @ w.T + bias) + residual.  x [..., k0] (contiguous rows), w [n, k0+k1]."""
+    L = _lib.load()
+    x = x.contiguous()
+    m, k0 = _rows2d(x, "x")
+    k1 = 0
+    if x2 is not None:
+        x2 = x2.contiguous()
+        m2, k1 = _rows2d(x2, "x2")
+        assert m2 == m
+    _chk(w, "w")
+    w = w.contiguous()
+    n = w.shape[0]
+    assert w.shape[1] == k0 + k1, (w.shape, k0, k1)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = residual.contiguous()
+    flags, rc, rs, rcols = 0, None, None, 0
+    if rotary is not None:
+        rc, rs, rcols = rotary
+        flags = 1
+    _lib.check(L.pram_linear_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(w), _p(bias), _p(residual),
+                                 n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+               "pram_linear_f32")
+    return out
+
+
+def bgemm_nt(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, ldc: Optional[int] = None) -> torch.Tensor:
+    """c[z] = alpha * a[z] @ b[z].T ; a [B,M,K], b [B,N,K] -> c [B,M,ldc] (view [:, :, :N] is the result)."""
+    L = _lib.load()
+    a, b = a.contiguous(), b.contiguous()
+    _chk(a, "a"), _chk(b, "b")
+    B, M, K = a.shape
+    N = b.shape[1]
+    ldc = ldc or N
+    c = torch.empty(B, M, ldc, device=a.device, dtype=torch.float32)
+    _lib.check(L.pram_bgemm_nt_f32(_p(a), K, M * K, _p(b), K, N * K, _p(c), ldc, M * ldc, B, M, N, K, float(alpha), _st()),
+               "pram_bgemm_nt_f32")
+    return c
+
+
+def layernorm_gelu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    L = _lib.load()
+    rows, cols = _rows2d(x, "x")
+    assert x.is_contiguous()
+    _lib.check(L.pram_layernorm_gelu_f32(_p(x), cols, _p(x), cols, _p(gamma), _p(beta), rows, cols, float(eps), _st()),
+               "pram_layernorm_gelu_f32")
+    return x
+
+
+def fourier_encoding(kpts: torch.Tensor, wr: torch.Tensor, cx: float, cy: float, scale: float):
+    """kpts [..., 2] -> (cos, sin) [..., 32]"""
+    L = _lib.load()
+    kpts = kpts.contiguous().float()
+    _chk(kpts, "kpts")
+    rows = kpts.numel() // 2
+    cos = torch.empty(*kpts.shape[:-1], 32, device=kpts.device, dtype=torch.float32)
+    sin = torch.empty_like(cos)
+    _lib.check(L.pram_fourier_encoding_f32(_p(kpts), _p(wr), float(cx), float(cy), float(scale), _p(cos), _p(sin), rows, _st()),
+               "pram_fourier_encoding_f32")
+    return cos, sin
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int,
+              scale: float, q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None,
+              want_lse: bool = False, out: Optional[torch.Tensor] = None):
+    """q/k/v: 2-D row-major views (possibly column slices of a wider buffer): q [batch*m_max, >=heads*64]."""
+    L = _lib.load()
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, nm)
+        assert t.dim() == 2 and t.stride(1) == 1
+    if out is None:
+        out = torch.empty(batch * m_max, heads * 64, device=q.device, dtype=torch.float32)
+    lse = torch.empty(batch, heads, m_max, device=q.device, dtype=torch.float32) if want_lse else None
+    _lib.check(L.pram_attention_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                    _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
+               "pram_attention_f32")
+    return (out, lse) if want_lse else out
+
+
+def attention_colmean(q: torch.Tensor, k: torch.Tensor, lse2: torch.Tensor, batch: int, heads: int, m_max: int,
+                      n_max: int, scale: float, q_lens=None, k_lens=None) -> torch.Tensor:
+    L = _lib.load()
+    out = torch.zeros(batch, n_max, device=q.device, dtype=torch.float32)
+    _lib.check(L.pram_attention_colmean_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(lse2), _p(out), _p(q_lens),
+                                            _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
+               "pram_attention_colmean_f32")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (str(device),)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, threshold: float,
+                   m_lens=None, n_lens=None, want_p: bool = False, dual_softmax: bool = False, n_valid: Optional[int] = None):
+    """dist [B, M, ldd] (first n_valid (default ldd) columns valid).  Returns dict with matches0/1 (int64),
+    matching_scores0/1 and optionally the full assignment matrix 'p' [B, M+1, N+1]."""
+    L = _lib.load()
+    _chk(dist, "dist")
+    assert dist.is_contiguous() and dist.dim() == 3
+    B, M, ldd = dist.shape
+    N = n_valid or ldd
+    ws = _workspace(L.pram_sinkhorn_workspace_bytes(B, M, N), dist.device)
+    m0 = torch.empty(B, M, device=dist.device, dtype=_INT64)
+    m1 = torch.empty(B, N, device=dist.device, dtype=_INT64)
+    s0 = torch.empty(B, M, device=dist.device, dtype=torch.float32)
+    s1 = torch.empty(B, N, device=dist.device, dtype=torch.float32)
+    p = torch.zeros(B, M + 1, N + 1, device=dist.device, dtype=torch.float32) if want_p else None
+    bs = bin_score.reshape(1).float()
+    if dual_softmax:
+        rc = L.pram_dual_softmax_match_f32(_p(dist), ldd, _p(m_lens), _p(n_lens), _p(bs), float(threshold), _p(p), N + 1,
+                                           _p(m0), _p(m1), _p(s0), _p(s1), B, M, N, _p(ws), _st())
+    else:
+        rc = L.pram_sinkhorn_match_f32(_p(dist), ldd, _p(m_lens), _p(n_lens), _p(bs), int(iters), float(threshold), _p(p),
+                                       N + 1, _p(m0), _p(m1), _p(s0), _p(s1), B, M, N, _p(ws), _st())
+    _lib.check(rc, "pram_sinkhorn_match_f32")
+    out = {"matches0": m0, "matches1": m1, "matching_scores0": s0, "matching_scores1": s1}
+    if want_p:
+        out["p"] = p
+    return out
+
+
+def adagml_prune(logit, thr, n_min_tokens, lens_in, x, cos, sin, ind, want_conf=False):
+    """-> (x_out, cos_out, sin_out, ind_out, lens_out int32 [S], n_below int32 [S], conf or None)"""
+    L = _lib.load()
+    S, T = logit.shape
+    ldx = x.shape[-1]
+    x_o, cos_o, sin_o, ind_o = torch.zeros_like(x), torch.zeros_like(cos), torch.zeros_like(sin), torch.zeros_like(ind)
+    lens_o = torch.zeros(S, device=x.device, dtype=torch.int32)
+    n_below = torch.zeros(S, device=x.device, dtype=torch.int32)
+    conf = torch.zeros(S, T, device=x.device, dtype=torch.float32) if want_conf else None
+    _lib.check(L.pram_adagml_prune_f32(_p(logit), float(thr), int(n_min_tokens), _p(lens_in), _p(x), _p(cos), _p(sin), _p(ind),
+                                       _p(x_o), _p(cos_o), _p(sin_o), _p(ind_o), _p(lens_o), _p(n_below), _p(conf), S, T, ldx, _st()),
+               "pram_adagml_prune_f32")
+    return x_o, cos_o, sin_o, ind_o, lens_o, n_below, conf
+
+
+def adagml_scatter(matches0, mscores0, ind0, ind1, lens0, m_full):
+    L = _lib.load()
+    B, T = matches0.shape
+    out_m = torch.full((B, m_full), -1, device=matches0.device, dtype=_INT64)
+    out_s = torch.zeros(B, m_full, device=matches0.device, dtype=torch.float32)
+    _lib.check(L.pram_adagml_scatter_f32(_p(matches0), _p(mscores0), _p(ind0), _p(ind1), _p(lens0), B, T, m_full, _p(out_m),
+                                         _p(out_s), _st()), "pram_adagml_scatter_f32")
+    return out_m, out_s
+
+
+# ------------------------------------------------------------------------------------- SFD2
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=None, residual=None, ks: int = 3,
+                stride: int = 1, relu: bool = False) -> torch.Tensor:
+    """x [B,H,W,Cin] contiguous NHWC; w [Cout,ks,ks,Cin]."""
+    L = _lib.load()
+    _chk(x, "x")
+    assert x.is_contiguous() and w.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    _lib.check(L.pram_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(w), _p(bias), _p(scale), _p(shift), _p(residual), _p(out),
+                                      Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f32")
+    return out
+
+
+def conv3x3_grouped_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, groups: int, relu: bool) -> torch.Tensor:
+    L = _lib.load()
+    assert x.is_contiguous() and w.is_contiguous()
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    _lib.check(L.pram_conv3x3_grouped_nhwc_f32(_p(x), B, H, W, Cc, _p(w), _p(scale), _p(shift), _p(out), groups, int(relu), _st()),
+               "pram_conv3x3_grouped_nhwc_f32")
+    return out
+
+
+def image_to_nhwc4(img: torch.Tensor) -> torch.Tensor:
+    L = _lib.load()
+    img = img.contiguous()
+    _chk(img, "image")
+    B, Cc, H, W = img.shape
+    assert Cc == 3
+    out = torch.empty(B, H, W, 4, device=img.device, dtype=torch.float32)
+    _lib.check(L.pram_image_to_nhwc4_f32(_p(img), _p(out), B, H, W, _st()), "pram_image_to_nhwc4_f32")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    L = _lib.load()
+    assert x.is_contiguous()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, H, W, device=x.device, dtype=torch.float32)
+    _lib.check(L.pram_nhwc_to_nchw_f32(_p(x), _p(out), B, H, W, Cc, _st()), "pram_nhwc_to_nchw_f32")
+    return out
+
+
+def score_map(logits_nhwc: torch.Tensor) -> torch.Tensor:
+    L = _lib.load()
+    assert logits_nhwc.is_contiguous() and logits_nhwc.shape[-1] == 65
+    B, Hc, Wc, _ = logits_nhwc.shape
+    out = torch.empty(B, Hc * 8, Wc * 8, device=logits_nhwc.device, dtype=torch.float32)
+    _lib.check(L.pram_score_map_f32(_p(logits_nhwc), _p(out), B, Hc, Wc, _st()), "pram_score_map_f32")
+    return out
+
+
+def simple_nms(score: torch.Tensor, radius: int) -> torch.Tensor:
+    L = _lib.load()
+    score = score.contiguous()
+    _chk(score, "score")
+    B, H, W = score.shape
+    out = torch.empty_like(score)
+    _lib.check(L.pram_simple_nms_f32(_p(score), _p(out), B, H, W, int(radius), _st()), "pram_simple_nms_f32")
+    return out
+
+
+def select_keypoints(nms: torch.Tensor, conf_th: float, min_keypoints: int, border: int, max_keypoints: int,
+                     fallback_ref: int = 0):
+    """-> kpts [B,k,2] (x,y), scores [B,k], counts [B] int32 (device)."""
+    L = _lib.load()
+    assert nms.is_contiguous()
+    B, H, W = nms.shape
+    k = int(max_keypoints)
+    ws = _workspace(L.pram_select_keypoints_workspace_bytes(B, H, W, k), nms.device)
+    kpts = torch.zeros(B, k, 2, device=nms.device, dtype=torch.float32)
+    scores = torch.zeros(B, k, device=nms.device, dtype=torch.float32)
+    counts = torch.zeros(B, device=nms.device, dtype=torch.int32)
+    _lib.check(L.pram_select_keypoints_f32(_p(nms), B, H, W, float(conf_th), int(min_keypoints), int(border), k,
+                                           int(fallback_ref), _p(kpts), _p(scores), _p(counts), _p(ws), _st()),
+               "pram_select_keypoints_f32")
+    return kpts, scores, counts
+
+
+def sample_nhwc(fmap: torch.Tensor, kpts: torch.Tensor, lens: Optional[torch.Tensor], s: int, l2norm: bool) -> torch.Tensor:
+    """fmap [B,fh,fw,C] NHWC, kpts [B,N,2] -> [B,N,C]"""
+    L = _lib.load()
+    assert fmap.is_contiguous()
+    kpts = kpts.contiguous()
+    B, fh, fw, Cc = fmap.shape
+    N = kpts.shape[1]
+    out = torch.zeros(B, N, Cc, device=fmap.device, dtype=torch.float32)
+    _lib.check(L.pram_sample_nhwc_f32(_p(fmap), B, fh, fw, Cc, _p(kpts), _p(lens), N, int(s), int(l2norm), _p(out), _st()),
+               "pram_sample_nhwc_f32")
+    return out
+
+
+def l2norm_rows_(x: torch.Tensor) -> torch.Tensor:
+    L = _lib.load()
+    assert x.is_contiguous()
+    cols = x.shape[-1]
+    _lib.check(L.pram_l2norm_rows_f32(_p(x), x.numel() // cols, cols, _st()), "pram_l2norm_rows_f32")
+    return x
+
+
+def score_lookup(score_map_: torch.Tensor, kpts: torch.Tensor, lens: Optional[torch.Tensor]) -> torch.Tensor:
+    L = _lib.load()
+    score_map_ = score_map_.contiguous()
+    kpts = kpts.contiguous()
+    B, H, W = score_map_.shape
+    Bk, N = kpts.shape[0], kpts.shape[1]
+    out = torch.zeros(Bk, N, device=kpts.device, dtype=torch.float32)
+    stride = 0 if B == 1 else H * W
+    _lib.check(L.pram_score_lookup_f32(_p(score_map_), stride, H, W, _p(kpts), _p(lens), Bk, N, _p(out), _st()),
+               "pram_score_lookup_f32")
+    return out

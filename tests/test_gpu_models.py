@@ -1,0 +1,228 @@
+"""GPU (MI355X): the model-level boundary (same load / forward() surface as the reference) against the CPU
+oracle and the golden vectors captured from the imported reference.  Tolerance: 1e-3 abs on fp32 outputs
+(north_star), tighter where written; indices bit-exact."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from pram_amd import weights as W
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _segnet(dev, C=113):
+    from pram_amd.nets.load_segnet import load_segnet
+    m = load_segnet('segnetvit', C, 256, 15, 1024)
+    m.load_state_dict(H.segnet_sd(C), strict=True)
+    return m.to(dev).eval()
+
+
+def _tokens(B, N):
+    toks = [W.synthetic_tokens(i, N) for i in range(B)]
+    return torch.stack([t[0] for t in toks]), torch.stack([t[1] for t in toks])
+
+
+@pytest.mark.parametrize("tag", ["b2_n512_c113", "b1_n300_c161"])
+def test_segnetvit_golden(dev, golden, tag):
+    g = golden(f"segnetvit_{tag}")
+    B, N, C = int(g["B"]), int(g["N"]), int(g["C"])
+    desc, kp = _tokens(B, N)
+    out = _segnet(dev, C)({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(B, 3, 480, 640)})["prediction"]
+    assert tuple(out.shape) == (B, N, C)
+    d = np.abs(H.subsample(out.cpu(), 8192).numpy() - g["logits_sub"]).max()
+    print(f"segnetvit {tag}: max |logit - golden| = {d:.2e}")
+    assert d < 1e-3
+    assert np.abs(out[:, :8].cpu().numpy() - g["logits_rows"]).max() < 1e-3
+    agree = (out.argmax(-1).cpu().numpy().astype(np.int16) == g["argmax"]).mean()
+    assert agree > 0.999, agree
+
+
+def test_segnetvit_full_size_vs_oracle(dev):
+    """BASELINE size (N = 2048, nc113) against the oracle."""
+    desc, kp = _tokens(1, 2048)
+    ref = R.segnetvit_forward(H.segnet_sd(113), desc, kp, (1, 3, 480, 640))
+    out = _segnet(dev)({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"]
+    d = H.maxdiff(out, ref)
+    print(f"segnetvit N=2048: max |logit - oracle| = {d:.2e}")
+    assert d < 1e-3
+    assert (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean() > 0.999
+
+
+def test_segnetvit_norm_keypoints_and_errors(dev):
+    m = _segnet(dev)
+    desc, kp = _tokens(1, 256)
+    nk = R.normalize_keypoints(kp, (1, 3, 480, 640))
+    a = m({"seg_descriptors": desc.to(dev), "norm_keypoints": nk.to(dev)})["prediction"]
+    b = m({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"]
+    assert H.maxdiff(a, b) < 1e-4
+    with pytest.raises(ValueError):
+        m({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev)})
+
+
+def test_segnetvit_ragged_batch(dev):
+    """extension: lens — every element equals its own B = 1 run bit for bit."""
+    m = _segnet(dev)
+    desc, kp = _tokens(3, 384)
+    lens = [384, 250, 129]
+    out = m({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(3, 3, 480, 640),
+             "lens": torch.tensor(lens, dtype=torch.int32, device=dev)})["prediction"]
+    for b, n in enumerate(lens):
+        solo = m({"seg_descriptors": desc[b:b + 1, :n].to(dev), "keypoints": kp[b:b + 1, :n].to(dev),
+                  "image": torch.empty(1, 3, 480, 640)})["prediction"]
+        assert torch.equal(out[b, :n], solo[0])
+
+
+def _gml(dev):
+    from pram_amd.nets.gml import GML
+    g = GML({})
+    g.load_state_dict(H.gml_sd(), strict=True)
+    return g.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag,key", [("m384_n512", "image_shape"), ("m256_n256_img", "image")])
+def test_gml_golden(dev, golden, tag, key):
+    g = golden(f"gml_{tag}")
+    data, _ = H.pair_data(0, int(g["m"]), int(g["n"]), key, device=dev)
+    net = _gml(dev)
+    r = net(data)
+    r0 = net.produce_matches(data, p=0.0)
+    assert r["matches0"].dtype == torch.int64 and tuple(r["matches0"].shape) == (1, int(g["m"]))
+    ds = np.abs(r0["matching_scores0"].cpu().numpy() - g["s0"]).max()
+    print(f"gml {tag}: max |score - golden| = {ds:.2e}")
+    assert ds < 1e-3
+    for got, want in ((r["matches0"], g["m0_def"]), (r["matches1"], g["m1_def"]), (r0["matches0"], g["m0_p0"]), (r0["matches1"], g["m1_p0"])):
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_gml_batch_of_pairs(dev):
+    """B = 3 pairs in one call == three B = 1 calls (the reference's matcher accepts a batch dim)."""
+    net = _gml(dev)
+    ds = [H.pair_data(i, 320, 320, device=dev)[0] for i in range(3)]
+    cat = {k: torch.cat([d[k] for d in ds], 0) for k in ds[0] if torch.is_tensor(ds[0][k])}
+    cat["image_shape0"] = cat["image_shape1"] = (1, 3, 640, 480)
+    rb = net.produce_matches(cat, p=0.0)
+    for i, d in enumerate(ds):
+        r1 = net.produce_matches(d, p=0.0)
+        assert torch.equal(rb["matches0"][i], r1["matches0"][0]) and torch.equal(rb["matching_scores0"][i], r1["matching_scores0"][0])
+
+
+def test_gml_full_size_vs_oracle(dev):
+    """2048 x 2048 (BASELINE C3 shape) against the oracle: indices exact, scores within 1e-3."""
+    data, gt = H.pair_data(0, 2048, 2048)
+    ref = R.gml_produce_matches(H.gml_sd(), data, p=0.2)
+    r = _gml(dev)({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()})
+    d = H.maxdiff(r["matching_scores0"], ref["matching_scores0"])
+    mism = (r["matches0"].cpu() != ref["matches0"]).sum().item()
+    print(f"gml 2048x2048: score diff {d:.2e}, mismatching indices {mism}, matches {(ref['matches0'] >= 0).sum().item()}")
+    assert d < 1e-3 and mism == 0
+
+
+def test_matcher_plugin_path(dev, golden):
+    """dynamic_load(matchers, 'gml')(conf) with a {'model': state_dict} checkpoint, as localizer.py:39-40 does."""
+    import pram_amd.localization.matchers as matchers
+    from pram_amd.localization.base_model import dynamic_load
+    from pram_amd.localization.match_features_batch import confs
+    g = golden("gml_m384_n512")
+    with tempfile.TemporaryDirectory() as td:
+        wp = os.path.join(td, "gml.pth")
+        torch.save({"model": H.gml_sd()}, wp)
+        conf = dict(confs["gml"]["model"], weight_path=wp)
+        model = dynamic_load(matchers, conf["name"])(conf).eval().to(dev)
+        data, _ = H.pair_data(0, 384, 512, device=dev)
+        m0 = model(data)["matches0"][0].cpu().numpy()
+    assert np.array_equal(m0, g["m0_def"][0])
+
+
+def _adagml(dev):
+    from pram_amd.nets.adagml import AdaGML
+    a = AdaGML({})
+    a.load_state_dict(H.adagml_sd(), strict=True)
+    return a.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag", ["m640_n768", "m300_n280"])
+def test_adagml_golden(dev, golden, tag):
+    g = golden(f"adagml_{tag}")
+    data, _ = H.pair_data(int(g["pair_index"]), int(g["m"]), int(g["n"]), device=dev)
+    probes = {}
+    r = _adagml(dev).produce_matches(data, p=0.0, probes=probes)
+    lens = probes["lens"].tolist()
+    ind0 = probes["ind"][0, :lens[0]].cpu().numpy()
+    ind1 = probes["ind"][1, :lens[1]].cpu().numpy()
+    print(f"adagml {tag}: stop {probes['stop_layer']} (golden {int(g['stop_layer'])}), survivors {lens} (golden {len(g['ind0'])}, {len(g['ind1'])})")
+    assert probes["stop_layer"] == int(g["stop_layer"])
+    assert np.array_equal(ind0, g["ind0"]) and np.array_equal(ind1, g["ind1"])
+    assert np.array_equal(r["matches0"].cpu().numpy(), g["m0_p0"])
+    assert np.abs(r["matching_scores0"].cpu().numpy() - g["s0"]).max() < 1e-3
+
+
+def _sfd2(dev):
+    from pram_amd.nets.sfd2 import ResNet4x
+    n = ResNet4x()
+    n.load_state_dict(H.sfd2_sd(), strict=True)
+    return n.to(dev).eval()
+
+
+def test_sfd2_small_batch_vs_oracle(dev, golden):
+    """2 frames of 96x128: dense maps within 1e-4, keypoints vs the reference (golden), fallback on element 0."""
+    net = _sfd2(dev)
+    img = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)])
+    o = R.sfd2_extract_local_global(H.sfd2_sd(), img, max_keypoints=64, min_keypoints=8)
+    r = net.extract_local_global({"image": img.to(dev)}, {"max_keypoints": 64, "min_keypoints": 8})
+    for k in ("score_map", "desc_map", "mid_features"):
+        d = H.maxdiff(r[k], o[k])
+        print(f"sfd2 small {k}: {d:.2e}")
+        assert tuple(r[k].shape) == tuple(o[k].shape) and d < 1e-4
+    for a, b in zip(r["global_descriptors"], o["global_descriptors"]):
+        assert tuple(a.shape) == tuple(b.shape) and H.maxdiff(a, b) < 1e-4
+    g = golden("sfd2_small_k64")
+    for b in range(2):
+        kp = r["keypoints"][b].cpu().numpy().astype(np.int16)
+        same = {tuple(x) for x in kp} & {tuple(x) for x in g[f"kp{b}"]}
+        print(f"sfd2 small frame {b}: {len(same)}/{len(g[f'kp{b}'])} keypoints identical to the reference (chained)")
+        assert len(same) >= 0.95 * len(g[f"kp{b}"])
+        assert tuple(r["descriptors"][b].shape) == (128, len(kp))
+
+
+def test_sfd2_full_frame_golden(dev, golden):
+    """480x640, k = 2048: dense maps vs golden sub-samples (1e-3), chained keypoint agreement, sample()."""
+    g = golden("sfd2_frame0")
+    net = _sfd2(dev)
+    img = W.synthetic_image(0)[None].to(dev)
+    r = net.extract_local_global({"image": img}, {"min_keypoints": 128, "max_keypoints": 2048})
+    for key, gk in (("score_map", "score_sub"), ("mid_features", "out4_sub"), ("desc_map", "desc_map_sub")):
+        d = np.abs(H.subsample(r[key].contiguous().cpu(), 8192).numpy() - g[gk]).max()
+        print(f"sfd2 frame0 {key}: {d:.2e}")
+        assert d < 1e-3
+    kp = r["keypoints"][0].cpu().numpy().astype(np.int16)
+    assert kp.shape == (2048, 2)
+    want = {tuple(x) for x in g["keypoints"]}
+    same = sum(tuple(x) in want for x in kp)
+    print(f"sfd2 frame0: {same}/2048 keypoints identical to the reference (chained, conv sums differ at 1e-7)")
+    assert same >= 2000
+    # stage-isolated: feed the reference keypoints, compare descriptors / seg descriptors
+    kref = torch.from_numpy(g["keypoints"].astype(np.float32)).to(dev)
+    sc, seg = net.sample(r["score_map"], r["mid_features"], kref, norm_desc=False)
+    assert tuple(seg.shape) == (256, 2048)
+    assert np.abs(seg[:, ::16].cpu().numpy() - g["seg_desc_sub"]).max() < 1e-3
+    _, d128 = net.sample(r["score_map"], r["desc_map"], kref, norm_desc=True)
+    assert np.abs(d128[:, ::16].cpu().numpy() - g["descriptors_sub"]).max() < 1e-3
+    assert np.abs(sc.cpu().numpy() - g["scores"]).max() < 1e-5
+
+
+def test_product_path_rejects_cpu(dev):
+    from pram_amd._lib import PramHipError
+    desc, kp = _tokens(1, 64)
+    with pytest.raises(PramHipError):
+        _segnet(dev)({"seg_descriptors": desc, "keypoints": kp, "image": torch.empty(1, 3, 480, 640)})
