@@ -159,9 +159,11 @@ int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int h, int w, 
  * logits NHWC [b][hc][wc][65] -> score [b][8hc][8wc] */
 int pram_score_map_f32(const float* logits, float* score, int batch, int hc, int wc, void* stream);
 
-/* simple_nms (nets/sfd2.py:20-35; K3): 1 + 2 suppression rounds, window 2r+1, exact equality. */
+/* simple_nms (nets/sfd2.py:20-35; K3): 1 + 2 suppression rounds, window 2r+1 (r <= 4), exact equality.
+ * workspace: pram_simple_nms_workspace_bytes (four fp32 images per frame). */
+size_t pram_simple_nms_workspace_bytes(int batch, int h, int w);
 int pram_simple_nms_f32(const float* score, float* nms, int batch, int h, int w, int radius,
-                        void* stream);
+                        void* workspace, void* stream);
 
 size_t pram_select_keypoints_workspace_bytes(int batch, int h, int w, int max_keypoints);
 

@@ -35,7 +35,8 @@ _SIGS = {
     "pram_image_to_nhwc4_f32": (I, [P, P, I, I, I, P]),
     "pram_nhwc_to_nchw_f32": (I, [P, P, I, I, I, I, P]),
     "pram_score_map_f32": (I, [P, P, I, I, I, P]),
-    "pram_simple_nms_f32": (I, [P, P, I, I, I, I, P]),
+    "pram_simple_nms_workspace_bytes": (SZ, [I, I, I]),
+    "pram_simple_nms_f32": (I, [P, P, I, I, I, I, P, P]),
     "pram_select_keypoints_workspace_bytes": (SZ, [I, I, I, I]),
     "pram_select_keypoints_f32": (I, [P, I, I, I, F, I, I, I, I, P, P, P, P, P]),
     "pram_sample_nhwc_f32": (I, [P, I, I, I, I, P, P, I, I, I, P, P]),

@@ -49,6 +49,8 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
     }
 
+    // loaders: clamped (always legal) addresses + select, no branches around the loads
+    const int nlast = p.cout - 1, klast = p.k - 4, ntap = p.ks * p.ks;
     auto la = [&](int pp, int kt) -> float4 {
         int tap, ci;
         if (CIN4) {
@@ -56,113 +58,154 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
             ci = 0;
         } else {
             const int k = kt * BK;
-            tap = k / p.cin;      // cin % 32 == 0: a chunk never straddles taps
+            tap = k / p.cin;      // cin % 32 == 0: a chunk never straddles taps (wave-uniform)
             ci = k - tap * p.cin + skq * 4;
         }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok[pp] && tap < p.ks * p.ks) {
-            const int ky = tap / p.ks, kx = tap - ky * p.ks;
-            const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
-            if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd)
-                v = *reinterpret_cast<const float4*>(base[pp] + ((size_t)iy * p.wd + ix) * p.cin + ci);
-        }
-        return v;
+        const int tc = min(tap, ntap - 1);
+        const int ky = tc / p.ks, kx = tc - ky * p.ks;
+        const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
+        const bool in = ok[pp] && tap < ntap && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+        const int iyc = min(max(iy, 0), p.h - 1), ixc = min(max(ix, 0), p.wd - 1);
+        return ld4_or_zero(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + ci, in);
     };
     auto lb = [&](int pp, int kt) -> float4 {
         const int col = col0 + srow + 32 * pp;
         const int k = kt * BK + skq * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col < p.cout && k < p.k) v = *reinterpret_cast<const float4*>(p.w + (size_t)col * p.k + k);
-        return v;
+        return ld4_or_zero(p.w + (size_t)min(col, nlast) * p.k + min(k, klast), col < p.cout && k < p.k);
     };
 
     f32x16 acc[2][2];
     mainloop(smem, la, lb, (p.k + BK - 1) / BK, acc);
 
+    // ---- epilogue: bias -> BN scale/shift -> residual -> ReLU; loads first, predicated stores last
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
+    const int mlast = p.m - 1;
+    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.cout);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = col0 + wn * 64 + ni * 32 + r;
-        if (col >= p.cout) continue;
-        const float bi = p.bias ? p.bias[col] : 0.f;
-        const float sc = p.scale ? p.scale[col] : 1.f;
-        const float sh = p.shift ? p.shift[col] : 0.f;
+        const int cc = min(col, nlast);
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float sh = p.scale ? p.shift[cc] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
+            float q[16];
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    q[e] = p.residual[(size_t)min(row0 + wm * 64 + acc_row(mi, e, h), mlast) * p.cout + cc];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = row0 + wm * 64 + acc_row(mi, e, h);
-                if (row >= p.m) continue;
                 float v = acc[mi][ni][e] + bi;
                 if (p.scale) v = v * sc + sh;
-                if (p.residual) v += p.residual[(size_t)row * p.cout + col];
+                if (p.residual) v += q[e];
                 if (p.relu) v = fmaxf(v, 0.f);
-                p.out[(size_t)row * p.cout + col] = v;
+                q[e] = v;
             }
+            if (full) {   // block-uniform fast path
+#pragma unroll
+                for (int e = 0; e < 16; ++e) p.out[(size_t)(row0 + wm * 64 + acc_row(mi, e, h)) * p.cout + col] = q[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + wm * 64 + acc_row(mi, e, h);
+                    if (row < p.m && col < p.cout) p.out[(size_t)row * p.cout + col] = q[e];
+                }
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------- grouped 3x3 (VALU)
 // groups = 32, 8 in / 8 out channels per group (72-deep dot products: too thin for MFMA tiles).
-// Workgroup = 64 consecutive pixels x 4 groups (one group per wave, so the 576 weights of a group
-// are wave-uniform and come from LDS as broadcasts); each lane owns one pixel of one group:
-// 9 taps x 2 float4 loads, 576 FMAs, 8 outputs.
+// Workgroup = 64 consecutive x-pixels x 4 output rows x 4 groups (one group per wave, so the 576
+// weights of a group are wave-uniform LDS broadcasts).  A lane owns 4 vertically adjacent pixels of
+// one group: each tap's 64 weights are read from LDS once (16 x ds_read_b128) and reused for the
+// 4 rows, so LDS issues 1 read per 16 FMAs; the 3x6 input window comes through L1.
 struct GConvArgs {
     const float* in; const float* w; const float* scale; const float* shift; float* out;
-    int batch, h, wd, c, groups, relu, npix;
+    int batch, h, wd, c, groups, relu, xtiles, ytiles;
 };
 
 __global__ __launch_bounds__(256) void gconv3x3_kernel(GConvArgs p) {
-    __shared__ float sw[4][8 * 72];
+    __shared__ __attribute__((aligned(16))) float sw[4][8 * 72];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y * 4 + wave;
-    // weights of group g: out channels g*8 .. +7, each [3][3][8] = 72 floats, contiguous 576 floats
     for (int i = lane; i < 576; i += 64) sw[wave][i] = p.w[(size_t)g * 576 + i];
     __syncthreads();
-    const int pix = blockIdx.x * 64 + lane;
-    if (pix >= p.npix) return;
-    const int x = pix % p.wd;
-    const int t = pix / p.wd;
-    const int y = t % p.h;
-    const int b = t / p.h;
+    int t = blockIdx.x;
+    const int xt = t % p.xtiles; t /= p.xtiles;
+    const int yt = t % p.ytiles;
+    const int b = t / p.ytiles;
+    const int x = xt * 64 + lane;
+    const int y0 = yt * 4;
+    const bool xok = x < p.wd;
     const float* ib = p.in + (size_t)b * p.h * p.wd * p.c + g * 8;
-    float acc[8];
+    float acc[4][8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int ro = 0; ro < 4; ++ro)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y + ky - 1;
+        for (int o = 0; o < 8; ++o) acc[ro][o] = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {   // one tap's 64 weights live at a time (full unroll spills)
+        const int ky = tap / 3, kx = tap - ky * 3;
+        {
+            float wt[8][8];
+            const float* ws = &sw[wave][tap * 8];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = x + kx - 1;
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd) {
-                const float* src = ib + ((size_t)iy * p.wd + ix) * p.c;
-                a0 = *reinterpret_cast<const float4*>(src);
-                a1 = *reinterpret_cast<const float4*>(src + 4);
+            for (int o = 0; o < 8; ++o) {
+                const float4 w0 = *reinterpret_cast<const float4*>(ws + o * 72);
+                const float4 w1 = *reinterpret_cast<const float4*>(ws + o * 72 + 4);
+                wt[o][0] = w0.x; wt[o][1] = w0.y; wt[o][2] = w0.z; wt[o][3] = w0.w;
+                wt[o][4] = w1.x; wt[o][5] = w1.y; wt[o][6] = w1.z; wt[o][7] = w1.w;
             }
-            const float xin[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const float* wt = &sw[wave][(ky * 3 + kx) * 8];
+            const int ix = x + kx - 1;
+            const bool cx_ok = xok && (unsigned)ix < (unsigned)p.wd;
+            const int ixc = min(max(ix, 0), p.wd - 1);
 #pragma unroll
-            for (int o = 0; o < 8; ++o)
+            for (int ro = 0; ro < 4; ++ro) {
+                const int iy = y0 + ro + ky - 1;
+                const bool ok = cx_ok && (unsigned)iy < (unsigned)p.h;
+                const int iyc = min(max(iy, 0), p.h - 1);
+                const float* src = ib + ((size_t)iyc * p.wd + ixc) * p.c;
+                float4 a0 = *reinterpret_cast<const float4*>(src);
+                float4 a1 = *reinterpret_cast<const float4*>(src + 4);
+                if (!ok) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
+                const float xin[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[o] = fmaf(xin[i], wt[o * 72 + i], acc[o]);
+                for (int o = 0; o < 8; ++o)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[ro][o] = fmaf(xin[i], wt[o][i], acc[ro][o]);
+            }
         }
     }
-    float res[8];
+    if (!xok) return;
+    float sc[8], sh[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-        const int ch = g * 8 + o;
-        float v = acc[o];
-        if (p.scale) v = v * p.scale[ch] + p.shift[ch];
-        if (p.relu) v = fmaxf(v, 0.f);
-        res[o] = v;
+        sc[o] = p.scale ? p.scale[g * 8 + o] : 1.f;
+        sh[o] = p.scale ? p.shift[g * 8 + o] : 0.f;
     }
-    float* dst = p.out + (size_t)pix * p.c + g * 8;
-    *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-    *reinterpret_cast<float4*>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+#pragma unroll
+    for (int ro = 0; ro < 4; ++ro) {
+        const int y = y0 + ro;
+        if (y >= p.h) break;
+        float res[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float v = acc[ro][o];
+            if (p.scale) v = v * sc[o] + sh[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            res[o] = v;
+        }
+        float* dst = p.out + (((size_t)b * p.h + y) * p.wd + x) * p.c + g * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+    }
 }
 
 __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int hw, int total) {
@@ -222,8 +265,8 @@ extern "C" int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, 
     PRAM_REQUIRE(groups > 0 && c == groups * 8 && groups % 4 == 0, "pram_conv3x3_grouped_nhwc_f32: needs 8 channels per group");
     PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv3x3_grouped_nhwc_f32: scale and shift go together");
     if (batch == 0) return PRAM_OK;
-    GConvArgs p{in, wgt, scale, shift, out, batch, h, w, c, groups, relu, batch * h * w};
-    hipLaunchKernelGGL(gconv3x3_kernel, dim3(cdiv(p.npix, 64), groups / 4), dim3(256), 0, (hipStream_t)stream, p);
+    GConvArgs p{in, wgt, scale, shift, out, batch, h, w, c, groups, relu, cdiv(w, 64), cdiv(h, 4)};
+    hipLaunchKernelGGL(gconv3x3_kernel, dim3(p.xtiles * p.ytiles * batch, groups / 4), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_conv3x3_grouped_nhwc_f32");
 }
 

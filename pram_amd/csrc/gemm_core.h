@@ -26,10 +26,18 @@ namespace gemm {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = 36, NT = 256;
 
-struct Smem {
+struct alignas(16) Smem {
     float a[2][BM * LDT];
     float b[2][BN * LDT];
 };  // 73,728 B -> two workgroups per CU
+
+// Branch-free guarded float4 load: the address is always legal (clamped by the caller), the value is
+// zeroed when the element is out of range.  Branching around each load makes hipcc serialise them.
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
 
 // ALoad: float4 operator()(int row_in_tile_slot p (0..3), int kt) -> A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3]
 // BLoad: same for the weight rows.

@@ -36,60 +36,86 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
     const int srow = tid >> 3, skq = tid & 7;
     const int row0 = tm * BM, col0 = tn * BN;
 
+    // loaders: clamped (always legal) addresses + select, no branches around the loads
+    const int mlast = p.m - 1, nlast = p.n - 1, klast = K - 4;
     auto la = [&](int pp, int kt) -> float4 {
         const int row = row0 + srow + 32 * pp;
         const int k = kt * BK + skq * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < p.m && k < K) {
-            const float* src = (k < p.k0) ? (a0 + (size_t)row * p.lda0 + k)
-                                          : (p.a1 + (size_t)row * p.lda1 + (k - p.k0));
-            v = *reinterpret_cast<const float4*>(src);
-        }
-        return v;
+        const int rc = min(row, mlast), kc = min(k, klast);
+        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
+        const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (a0 + (size_t)rc * p.lda0 + kc);
+        return ld4_or_zero(src, row < p.m && k < K);
     };
     auto lb = [&](int pp, int kt) -> float4 {
         const int col = col0 + srow + 32 * pp;
         const int k = kt * BK + skq * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col < p.n && k < K) v = *reinterpret_cast<const float4*>(w + (size_t)col * K + k);
-        return v;
+        return ld4_or_zero(w + (size_t)min(col, nlast) * K + min(k, klast), col < p.n && k < K);
     };
 
     f32x16 acc[2][2];
     mainloop(smem, la, lb, (K + BK - 1) / BK, acc);
 
+    // ---- epilogue: all loads first (clamped addresses), then arithmetic, then predicated stores
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int cbase = col0 + wn * 64;
     const bool rot = (p.flags & PRAM_LIN_ROTARY) && cbase < p.rot_cols;
+    const int c0 = cbase + r, c1 = cbase + 32 + r;
+    const bool c0ok = c0 < p.n, c1ok = c1 < p.n;
+    const int c0c = min(c0, nlast), c1c = min(c1, nlast);
+    const float b0 = p.bias ? p.bias[c0c] : 0.f, b1 = p.bias ? p.bias[c1c] : 0.f;
+    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+        const int rbase = row0 + wm * 64;
+        float rc_[16], rs_[16], q0[16], q1[16];
+        if (rot) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t rr = (size_t)min(rbase + acc_row(mi, e, h), mlast) * 32 + r;
+                rc_[e] = p.rcos[rr];
+                rs_[e] = p.rsin[rr];
+            }
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t rr = (size_t)min(rbase + acc_row(mi, e, h), mlast) * p.ldr;
+                q0[e] = p.residual[rr + c0c];
+                q1[e] = p.residual[rr + c1c];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int row = row0 + wm * 64 + acc_row(mi, e, h);
-            if (row >= p.m) continue;
-            float v0 = acc[mi][0][e], v1 = acc[mi][1][e];
-            const int c0 = cbase + r, c1 = cbase + 32 + r;
-            if (p.bias) {
-                if (c0 < p.n) v0 += p.bias[c0];
-                if (c1 < p.n) v1 += p.bias[c1];
-            }
-            v0 *= p.alpha;
-            v1 *= p.alpha;
+            float v0 = (acc[mi][0][e] + b0) * p.alpha;
+            float v1 = (acc[mi][1][e] + b1) * p.alpha;
             if (rot) {
-                const float c = p.rcos[(size_t)row * 32 + r], s = p.rsin[(size_t)row * 32 + r];
-                const float e0 = v0 * c - v1 * s;   // even dim: t0*cos + (-t1)*sin
-                const float o0 = v1 * c + v0 * s;   // odd dim : t1*cos + t0*sin
+                const float e0 = v0 * rc_[e] - v1 * rs_[e];   // even dim: t0*cos + (-t1)*sin
+                const float o0 = v1 * rc_[e] + v0 * rs_[e];   // odd dim : t1*cos + t0*sin
                 v0 = e0;
                 v1 = o0;
             }
-            if (p.residual) {
-                if (c0 < p.n) v0 += p.residual[(size_t)row * p.ldr + c0];
-                if (c1 < p.n) v1 += p.residual[(size_t)row * p.ldr + c1];
+            if (p.residual) { v0 += q0[e]; v1 += q1[e]; }
+            q0[e] = v0;
+            q1[e] = v1;
+        }
+        if (full) {   // block-uniform fast path: no per-element predicates
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float* o = out + (size_t)(rbase + acc_row(mi, e, h)) * p.ldo;
+                o[c0] = q0[e];
+                o[c1] = q1[e];
             }
-            if (c0 < p.n) out[(size_t)row * p.ldo + c0] = v0;
-            if (c1 < p.n) out[(size_t)row * p.ldo + c1] = v1;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + acc_row(mi, e, h);
+                if (row < p.m) {
+                    if (c0ok) out[(size_t)row * p.ldo + c0] = q0[e];
+                    if (c1ok) out[(size_t)row * p.ldo + c1] = q1[e];
+                }
+            }
         }
     }
 }

@@ -29,88 +29,79 @@ __global__ __launch_bounds__(256) void score_map_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- K3: simple_nms
-// One workgroup = 32x32 output pixels; the five chained (2r+1)^2 max-pools need a 5r halo, all of
-// it staged in LDS once and consumed by separable row/column passes.  Out-of-image pixels are -inf
-// in score buffers and 0 in masks (max_pool2d's implicit padding); values whose window leaves the
-// staged tile are garbage but only ever feed other garbage — the central 32x32 is exact.
+// Five chained (2r+1)^2 max-pools (1 on the scores, then 2 x {mask, suppressed scores}).  Each pool is
+// one launch: a 32x32 output tile + r halo staged in LDS, separable row/column max, and the
+// stage's elementwise rule fused behind it.  The intermediate maps (mask, suppressed scores) are
+// fp32 images that stay L2-resident (1.2 MB per frame).  Out-of-image pixels are -inf for score
+// pools and 0 for mask pools (max_pool2d's implicit padding); all comparisons are exact fp32.
 constexpr int NMS_T = 32;
 constexpr int NMS_RMAX = 4;
-constexpr int NMS_S = NMS_T + 10 * NMS_RMAX;  // 72
 
-struct NmsSmem {
-    float s[NMS_S * NMS_S];   // scores
-    float x[NMS_S * NMS_S];   // pool input (mask as 0/1, or suppressed scores)
-    float t[NMS_S * NMS_S];   // row-pass temp
-    float p[NMS_S * NMS_S];   // pool output
-    unsigned char mask[NMS_S * NMS_S];
-    unsigned char supp[NMS_S * NMS_S];
-    unsigned char inside[NMS_S * NMS_S];
-};
-
-__device__ __forceinline__ void nms_pool(const float* __restrict__ src, float* __restrict__ tmp, float* __restrict__ dst,
-                                         int side, int r) {
-    const int n = side * side;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int y = i / side, x = i - y * side;
-        float m = -INFINITY;
-        const int lo = max(0, x - r), hi = min(side - 1, x + r);
-        for (int xx = lo; xx <= hi; ++xx) m = fmaxf(m, src[y * side + xx]);
-        tmp[i] = m;
+// STAGE 0: mask  = (s == pool(s))
+// STAGE 1: in = mask;  supp = pool(mask) > 0;  x = supp ? 0 : s           -> outputs x, supp
+// STAGE 2: in = x;     new = (x == pool(x)) & !supp;  mask |= new         -> output mask (or final scores)
+template <int R, int STAGE>
+__global__ __launch_bounds__(256) void nms_stage_kernel(const float* __restrict__ in, const float* __restrict__ score,
+                                                        const float* __restrict__ supp_in, const float* __restrict__ mask_in,
+                                                        float* __restrict__ out0, float* __restrict__ out1, int h, int w,
+                                                        int final_scores) {
+    constexpr int S = NMS_T + 2 * R;
+    __shared__ float tile[S][S + 1];
+    __shared__ float rowm[S][NMS_T + 1];
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * NMS_T, x0 = blockIdx.x * NMS_T;
+    const size_t off = (size_t)b * h * w;
+    const float pad = (STAGE == 1) ? 0.f : -INFINITY;
+    for (int i = threadIdx.x; i < S * S; i += 256) {
+        const int ly = i / S, lx = i - ly * S;
+        const int gy = y0 + ly - R, gx = x0 + lx - R;
+        const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+        tile[ly][lx] = ok ? in[off + (size_t)gy * w + gx] : pad;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int y = i / side, x = i - y * side;
-        float m = -INFINITY;
-        const int lo = max(0, y - r), hi = min(side - 1, y + r);
-        for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, tmp[yy * side + x]);
-        dst[i] = m;
+    for (int i = threadIdx.x; i < S * NMS_T; i += 256) {      // row pass: S rows x 32 output columns
+        const int ly = i / NMS_T, lx = i - ly * NMS_T;
+        float m = tile[ly][lx];
+#pragma unroll
+        for (int d = 1; d <= 2 * R; ++d) m = fmaxf(m, tile[ly][lx + d]);
+        rowm[ly][lx] = m;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < NMS_T * NMS_T; i += 256) {  // column pass + stage rule
+        const int ly = i / NMS_T, lx = i - ly * NMS_T;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= h || gx >= w) continue;
+        float m = rowm[ly][lx];
+#pragma unroll
+        for (int d = 1; d <= 2 * R; ++d) m = fmaxf(m, rowm[ly + d][lx]);
+        const size_t g = off + (size_t)gy * w + gx;
+        const float c = tile[ly + R][lx + R];
+        if (STAGE == 0) {
+            out0[g] = (c == m) ? 1.f : 0.f;
+        } else if (STAGE == 1) {
+            const bool sp = m > 0.f;
+            out0[g] = sp ? 0.f : score[g];
+            out1[g] = sp ? 1.f : 0.f;
+        } else {
+            const bool keep = (mask_in[g] != 0.f) || ((c == m) && supp_in[g] == 0.f);
+            out0[g] = final_scores ? (keep ? score[g] : 0.f) : (keep ? 1.f : 0.f);
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int h, int w, int r) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
-    NmsSmem& sm = *reinterpret_cast<NmsSmem*>(raw);
-    const int side = NMS_T + 10 * r;
-    const int halo = 5 * r;
-    const int b = blockIdx.z;
-    const int y0 = blockIdx.y * NMS_T - halo, x0 = blockIdx.x * NMS_T - halo;
-    const float* img = score + (size_t)b * h * w;
-    const int n = side * side;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int ly = i / side, lx = i - ly * side;
-        const int gy = y0 + ly, gx = x0 + lx;
-        const bool in = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
-        sm.inside[i] = in;
-        sm.s[i] = in ? img[(size_t)gy * w + gx] : -INFINITY;
-    }
-    __syncthreads();
-    nms_pool(sm.s, sm.t, sm.p, side, r);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) sm.mask[i] = sm.inside[i] && (sm.s[i] == sm.p[i]);
-    __syncthreads();
-    for (int round = 0; round < 2; ++round) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) sm.x[i] = sm.inside[i] ? (sm.mask[i] ? 1.f : 0.f) : -INFINITY;
-        __syncthreads();
-        nms_pool(sm.x, sm.t, sm.p, side, r);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const bool sp = sm.p[i] > 0.f;
-            sm.supp[i] = sp;
-            sm.x[i] = sm.inside[i] ? (sp ? 0.f : sm.s[i]) : -INFINITY;
-        }
-        __syncthreads();
-        nms_pool(sm.x, sm.t, sm.p, side, r);
-        for (int i = threadIdx.x; i < n; i += blockDim.x)
-            if (sm.inside[i] && (sm.x[i] == sm.p[i]) && !sm.supp[i]) sm.mask[i] = 1;
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < NMS_T * NMS_T; i += blockDim.x) {
-        const int ty = i / NMS_T, tx = i - ty * NMS_T;
-        const int gy = blockIdx.y * NMS_T + ty, gx = blockIdx.x * NMS_T + tx;
-        if (gy < h && gx < w) {
-            const int li = (ty + halo) * side + tx + halo;
-            out[((size_t)b * h + gy) * w + gx] = sm.mask[li] ? sm.s[li] : 0.f;
-        }
-    }
+template <int R>
+static void nms_launch(const float* score, float* out, float* ws, int batch, int h, int w, hipStream_t st) {
+    const size_t n = (size_t)batch * h * w;
+    float* mask = ws;           // [n]
+    float* x = ws + n;          // [n] suppressed scores
+    float* supp = ws + 2 * n;   // [n]
+    float* mask2 = ws + 3 * n;  // [n]
+    dim3 grid(cdiv(w, NMS_T), cdiv(h, NMS_T), batch), blk(256);
+    hipLaunchKernelGGL((nms_stage_kernel<R, 0>), grid, blk, 0, st, score, score, nullptr, nullptr, mask, nullptr, h, w, 0);
+    hipLaunchKernelGGL((nms_stage_kernel<R, 1>), grid, blk, 0, st, mask, score, nullptr, nullptr, x, supp, h, w, 0);
+    hipLaunchKernelGGL((nms_stage_kernel<R, 2>), grid, blk, 0, st, x, score, supp, mask, mask2, nullptr, h, w, 0);
+    hipLaunchKernelGGL((nms_stage_kernel<R, 1>), grid, blk, 0, st, mask2, score, nullptr, nullptr, x, supp, h, w, 0);
+    hipLaunchKernelGGL((nms_stage_kernel<R, 2>), grid, blk, 0, st, x, score, supp, mask2, out, nullptr, h, w, 1);
 }
 
 // ---------------------------------------------------------------- K4: keypoint selection
@@ -387,17 +378,23 @@ extern "C" int pram_score_map_f32(const float* logits, float* score, int batch, 
     return pram_launch_status("pram_score_map_f32");
 }
 
-extern "C" int pram_simple_nms_f32(const float* score, float* nms, int batch, int h, int w, int radius, void* stream) {
-    PRAM_REQUIRE(score && nms, "pram_simple_nms_f32: null pointer");
+extern "C" size_t pram_simple_nms_workspace_bytes(int batch, int h, int w) { return (size_t)batch * h * w * 4 * sizeof(float); }
+
+extern "C" int pram_simple_nms_f32(const float* score, float* nms, int batch, int h, int w, int radius, void* workspace,
+                                   void* stream) {
+    PRAM_REQUIRE(score && nms && workspace, "pram_simple_nms_f32: null pointer");
     PRAM_REQUIRE(radius >= 0 && radius <= NMS_RMAX, "pram_simple_nms_f32: radius %d > %d", radius, NMS_RMAX);
+    PRAM_REQUIRE(score != nms, "pram_simple_nms_f32: in-place is not supported");
     if (batch == 0) return PRAM_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsSmem));
-        attr_set = true;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    switch (radius) {
+        case 0: nms_launch<0>(score, nms, ws, batch, h, w, st); break;
+        case 1: nms_launch<1>(score, nms, ws, batch, h, w, st); break;
+        case 2: nms_launch<2>(score, nms, ws, batch, h, w, st); break;
+        case 3: nms_launch<3>(score, nms, ws, batch, h, w, st); break;
+        default: nms_launch<4>(score, nms, ws, batch, h, w, st); break;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(cdiv(w, NMS_T), cdiv(h, NMS_T), batch), dim3(256), sizeof(NmsSmem), (hipStream_t)stream,
-                       score, nms, h, w, radius);
     return pram_launch_status("pram_simple_nms_f32");
 }
 

@@ -59,9 +59,9 @@ class AdaGML(GML):
                 "pr0_w": f(p + ".predict.0.weight"), "pr0_b": f(p + ".predict.0.bias"),
                 "pr1_w": f(p + ".predict.1.weight"), "pr1_b": f(p + ".predict.1.bias"),
                 # N 1 -> 4 rows (zero pad) keeps the logit column 16-B aligned; column 0 is the logit
-                "pr3_w": torch.cat([sd[p + ".predict.3.weight"].detach().float(),
+                "pr3_w": torch.cat([sd[p + ".predict.3.weight"].detach().float().cpu(),
                                     torch.zeros(3, sd[p + ".predict.3.weight"].shape[1])], 0).contiguous().to(dev),
-                "pr3_b": torch.cat([sd[p + ".predict.3.bias"].detach().float(), torch.zeros(3)]).contiguous().to(dev),
+                "pr3_b": torch.cat([sd[p + ".predict.3.bias"].detach().float().cpu(), torch.zeros(3)]).contiguous().to(dev),
             })
         P["pool"] = pools
         return P

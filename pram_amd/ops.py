@@ -101,6 +101,11 @@ def fourier_encoding(kpts: torch.Tensor, wr: torch.Tensor, cx: float, cy: float,
     return cos, sin
 
 
+# bench.py's roofline probe: when set to a list, every attention launch is bracketed by HIP events on the
+# launch stream and (algorithmic flops, start, stop) is appended.  None (default) = no events.
+attention_probe = None
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int,
               scale: float, q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None,
               want_lse: bool = False, out: Optional[torch.Tensor] = None):
@@ -112,9 +117,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if out is None:
         out = torch.empty(batch * m_max, heads * 64, device=q.device, dtype=torch.float32)
     lse = torch.empty(batch, heads, m_max, device=q.device, dtype=torch.float32) if want_lse else None
+    probe = attention_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.pram_attention_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
                                     _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
                "pram_attention_f32")
+    if probe is not None:
+        e1.record()
+        # algorithmic FLOPs of QK^T + PV at the padded sizes: 4 * m * n * 64 per (batch, head)
+        probe.append((4.0 * m_max * n_max * 64 * heads * batch, e0, e1))
     return (out, lse) if want_lse else out
 
 
@@ -131,8 +144,8 @@ def attention_colmean(q: torch.Tensor, k: torch.Tensor, lse2: torch.Tensor, batc
 _ws_cache = {}
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (str(device),)
+def _workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
+    key = (str(device), tag)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
@@ -256,7 +269,8 @@ def simple_nms(score: torch.Tensor, radius: int) -> torch.Tensor:
     _chk(score, "score")
     B, H, W = score.shape
     out = torch.empty_like(score)
-    _lib.check(L.pram_simple_nms_f32(_p(score), _p(out), B, H, W, int(radius), _st()), "pram_simple_nms_f32")
+    ws = _workspace(L.pram_simple_nms_workspace_bytes(B, H, W), score.device, "nms")
+    _lib.check(L.pram_simple_nms_f32(_p(score), _p(out), B, H, W, int(radius), _p(ws), _st()), "pram_simple_nms_f32")
     return out
 
 

@@ -1,0 +1,84 @@
+"""Batched per-query hot path: SFD2 extract -> sample -> SegNetViT recognise -> GML/AdaGML match.
+
+Reproduces the model-call sequence of the reference's per-query loop
+(localization/loc_by_rec_online.py:109-133 followed by the matcher call of
+localization/singlemap3d.py:143-154) for a batch of independent query frames, entirely on the
+device: ragged keypoint counts travel as an int32 ``counts`` array, nothing synchronises with the
+host until the caller reads the result record.  Queries shard across GPUs with no data-path
+collective; ``gather_records`` is the single RCCL all-gather of the fixed-size result records
+(SURVEY.md §8(e)).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+
+class QueryPipeline:
+    def __init__(self, sfd2, segnet, matcher, max_keypoints: int = 2048, min_keypoints: int = 128):
+        self.sfd2, self.segnet, self.matcher = sfd2, segnet, matcher
+        self.cfg = {'min_keypoints': min_keypoints, 'max_keypoints': max_keypoints}
+
+    @torch.no_grad()
+    def run(self, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm") -> Dict[str, torch.Tensor]:
+        """images [B,3,H,W] normalised fp32 on the GPU.  ref: reference-frame sets to match against
+        (descriptors [B,Nr,128], keypoints [B,Nr,2], scores [B,Nr], optional lens int32 [B]).
+        stages: any of 'e' (extract), 'r' (recognise), 'm' (match)."""
+        B, _, H, W = images.shape
+        ex = self.sfd2.extract_batched(images, self.cfg, per_image_fallback=True)
+        kpts, scores, counts = ex['keypoints'], ex['scores'], ex['counts']
+        out = {'keypoints': kpts, 'scores': scores, 'counts': counts, 'descriptors': ex['descriptors']}
+        if 'r' in stages:
+            _, seg = self.sfd2.sample_batched(ex['score_map'], ex['mid_features'], kpts, counts, norm_desc=False)
+            pred = self.segnet({'seg_descriptors': seg, 'keypoints': kpts, 'image': images, 'lens': counts})['prediction']
+            out['prediction'] = pred
+            out['landmark'] = ops.row_argmax(pred) if hasattr(ops, 'row_argmax') else None
+        if 'm' in stages and ref is not None:
+            data = {
+                'descriptors0': ex['descriptors'], 'keypoints0': kpts, 'scores0': scores, 'lens0': counts,
+                # the reference hands the matcher (1, 3, width, height) (singlemap3d.py:147,152)
+                'image_shape0': (1, 3, W, H),
+                'descriptors1': ref['descriptors'], 'keypoints1': ref['keypoints'], 'scores1': ref['scores'],
+                'image_shape1': (1, 3, W, H),
+            }
+            if 'lens' in ref:
+                data['lens1'] = ref['lens']
+            m = self.matcher.produce_matches(data) if hasattr(self.matcher, 'produce_matches') else self.matcher(data)
+            out['matches0'] = m['matches0']
+            out['matching_scores0'] = m['matching_scores0']
+        return out
+
+    @staticmethod
+    def pack_record(out: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Fixed-size per-query record [B, k, 6] fp32: x, y, score, landmark id, match index, match score."""
+        B, k = out['scores'].shape
+        rec = torch.zeros(B, k, 6, device=out['scores'].device, dtype=torch.float32)
+        rec[:, :, 0:2] = out['keypoints']
+        rec[:, :, 2] = out['scores']
+        if out.get('landmark') is not None:
+            rec[:, :, 3] = out['landmark'].float()
+        if 'matches0' in out:
+            rec[:, :, 4] = out['matches0'].float()
+            rec[:, :, 5] = out['matching_scores0']
+        return rec
+
+
+def gather_records(rec: torch.Tensor) -> torch.Tensor:
+    """One all-gather of the result records over RCCL/xGMI (backend 'nccl' on ROCm; gloo on CPU tests)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec
+    ws = dist.get_world_size()
+    full = torch.empty((ws * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
+    dist.all_gather_into_tensor(full, rec.contiguous())
+    return full
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous chunk [lo, hi) of ``n_items`` queries for ``rank`` (balanced; first ranks get the remainder)."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
