@@ -202,9 +202,14 @@ def main():
     attn_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in probe)
     attn_flops = sum(f for f, _, _ in probe)
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+    traffic = None
+    try:   # HBM bytes per attention launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.md)
+        traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "mfma", "kernel": "attention_kernel (f32 MFMA flash attention)", "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "launches_per_step": len(probe), "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(attn_flops / max(1, len(probe)) / 512.0), "launches_per_step": len(probe), "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
                 "attention_share_of_step": round(attn_ms / (dt / args.steps * 1e3), 3)}
 
     if rank == 0:

@@ -122,11 +122,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
             const float* sk = s.k[cur];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            // K fragments are software-prefetched one chunk ahead: a wave issues the ds_read_b128 pair of
+            // chunk c+1 before the 8 MFMAs of chunk c, so the LDS latency hides under 512 matrix cycles.
+            float4 kA0, kA1, kB0, kB1;
+            auto kload = [&](int c, float4& k0, float4& k1) {
                 const int slot = (2 * c + h) ^ (r & 15);   // (key & 15) == (r & 15) for key = 32t + r
-                const float4 k0 = *reinterpret_cast<const float4*>(sk + r * D + (slot << 2));
-                const float4 k1 = *reinterpret_cast<const float4*>(sk + (32 + r) * D + (slot << 2));
+                k0 = *reinterpret_cast<const float4*>(sk + r * D + (slot << 2));
+                k1 = *reinterpret_cast<const float4*>(sk + (32 + r) * D + (slot << 2));
+            };
+            auto kmma = [&](int c, const float4& k0, const float4& k1) {
                 const float a0[4] = {k0.x, k0.y, k0.z, k0.w};
                 const float a1[4] = {k1.x, k1.y, k1.z, k1.w};
                 const float bq[4] = {qf[c].x, qf[c].y, qf[c].z, qf[c].w};
@@ -135,6 +139,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                     st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[j], st[0], 0, 0, 0);
                     st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[j], st[1], 0, 0, 0);
                 }
+            };
+            // sched_barrier(0) pins "prefetch, then MFMAs": hipcc otherwise sinks each ds_read next to its use
+            kload(0, kA0, kA1);
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                kload(c + 1, kB0, kB1);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(c, kA0, kA1);
+                if (c + 2 < 8) kload(c + 2, kA0, kA1);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(c + 1, kB0, kB1);
             }
             // ---- mask keys beyond klen (last tile only)
             if (!more && (klen & (BKV - 1))) {
@@ -167,18 +182,40 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             m_run = m_new;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
-            // ---- Oᵀ += Vᵀ · Pᵀ
+            // ---- Oᵀ += Vᵀ · Pᵀ   (V fragments prefetched 4 keys = 8 MFMAs ahead)
             const float* sv = s.v[cur];
+            float vA[4][2], vB[4][2];
+            auto vload = [&](int t, int e0, float (&vv)[4][2]) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = t * 32 + key_of(e, h);
-                    const float v0 = sv[key * D + r];
-                    const float v1 = sv[key * D + 32 + r];
-                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[t][e], oacc[0], 0, 0, 0);
-                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[t][e], oacc[1], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    const int key = t * 32 + key_of(e0 + i, h);
+                    vv[i][0] = sv[key * D + r];
+                    vv[i][1] = sv[key * D + 32 + r];
                 }
+            };
+            auto vmma = [&](int t, int e0, const float (&vv)[4][2]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[i][0], st[t][e0 + i], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[i][1], st[t][e0 + i], oacc[1], 0, 0, 0);
+                }
+            };
+            vload(0, 0, vA);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                vload(t, 4, vB);
+                __builtin_amdgcn_sched_barrier(0);
+                vmma(t, 0, vA);
+                vload(t, 8, vA);
+                __builtin_amdgcn_sched_barrier(0);
+                vmma(t, 4, vB);
+                vload(t, 12, vB);
+                __builtin_amdgcn_sched_barrier(0);
+                vmma(t, 8, vA);
+                if (t == 0) vload(1, 0, vA);
+                __builtin_amdgcn_sched_barrier(0);
+                vmma(t, 12, vB);
+            }
         }
         if (more) lstore(cur ^ 1);
         __syncthreads();

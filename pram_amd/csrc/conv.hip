@@ -19,10 +19,12 @@ struct ConvArgs {
     int tiles_m, tiles_n;
 };
 
-template <bool CIN4>
+template <bool CIN4, int MI, int WN>
 __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
     using namespace gemm;
-    __shared__ Smem smem;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -32,11 +34,11 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
     const int pad = p.ks >> 1;
 
     // per-thread staging rows: decompose the output pixel once
-    int iy0[4], ix0[4];
-    const float* base[4];
-    bool ok[4];
+    int iy0[C::PA], ix0[C::PA];
+    const float* base[C::PA];
+    bool ok[C::PA];
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
+    for (int pp = 0; pp < C::PA; ++pp) {
         const int row = row0 + srow + 32 * pp;
         ok[pp] = row < p.m;
         const int rr = ok[pp] ? row : 0;
@@ -51,8 +53,7 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
 
     // loaders: clamped (always legal) addresses + select, no branches around the loads
     const int nlast = p.cout - 1, klast = p.k - 4, ntap = p.ks * p.ks;
-    auto la = [&](int pp, int kt) -> float4 {
-        int tap, ci;
+    auto tap_of = [&](int kt, int& tap, int& ci) {
         if (CIN4) {
             tap = kt * 8 + skq;   // one tap (4 padded channels) per float4
             ci = 0;
@@ -61,27 +62,39 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
             tap = k / p.cin;      // cin % 32 == 0: a chunk never straddles taps (wave-uniform)
             ci = k - tap * p.cin + skq * 4;
         }
+    };
+    auto la = [&](int pp, int kt) -> float4 {
+        int tap, ci;
+        tap_of(kt, tap, ci);
+        const int tc = min(tap, ntap - 1);
+        const int ky = tc / p.ks, kx = tc - ky * p.ks;
+        const int iyc = min(max(iy0[pp] + ky, 0), p.h - 1), ixc = min(max(ix0[pp] + kx, 0), p.wd - 1);
+        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + ci);
+    };
+    auto oka = [&](int pp, int kt) -> bool {
+        int tap, ci;
+        tap_of(kt, tap, ci);
         const int tc = min(tap, ntap - 1);
         const int ky = tc / p.ks, kx = tc - ky * p.ks;
         const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
-        const bool in = ok[pp] && tap < ntap && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
-        const int iyc = min(max(iy, 0), p.h - 1), ixc = min(max(ix, 0), p.wd - 1);
-        return ld4_or_zero(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + ci, in);
+        return ok[pp] && tap < ntap && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
     auto lb = [&](int pp, int kt) -> float4 {
         const int col = col0 + srow + 32 * pp;
         const int k = kt * BK + skq * 4;
-        return ld4_or_zero(p.w + (size_t)min(col, nlast) * p.k + min(k, klast), col < p.cout && k < p.k);
+        return *reinterpret_cast<const float4*>(p.w + (size_t)min(col, nlast) * p.k + min(k, klast));
     };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.cout && (kt * BK + skq * 4) < p.k; };
 
-    f32x16 acc[2][2];
-    mainloop(smem, la, lb, (p.k + BK - 1) / BK, acc);
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, la, oka, lb, okb, (p.k + BK - 1) / BK, acc);
 
     // ---- epilogue: bias -> BN scale/shift -> residual -> ReLU; loads first, predicated stores last
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int mlast = p.m - 1;
+    const int rbase = row0 + wm * 32 * MI;
     const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.cout);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -91,12 +104,12 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
         const float sc = p.scale ? p.scale[cc] : 1.f;
         const float sh = p.scale ? p.shift[cc] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             float q[16];
             if (p.residual) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    q[e] = p.residual[(size_t)min(row0 + wm * 64 + acc_row(mi, e, h), mlast) * p.cout + cc];
+                    q[e] = p.residual[(size_t)min(rbase + acc_row(mi, e, h), mlast) * p.cout + cc];
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -108,11 +121,11 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
             }
             if (full) {   // block-uniform fast path
 #pragma unroll
-                for (int e = 0; e < 16; ++e) p.out[(size_t)(row0 + wm * 64 + acc_row(mi, e, h)) * p.cout + col] = q[e];
+                for (int e = 0; e < 16; ++e) p.out[(size_t)(rbase + acc_row(mi, e, h)) * p.cout + col] = q[e];
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = row0 + wm * 64 + acc_row(mi, e, h);
+                    const int row = rbase + acc_row(mi, e, h);
                     if (row < p.m && col < p.cout) p.out[(size_t)row * p.cout + col] = q[e];
                 }
             }
@@ -250,11 +263,19 @@ extern "C" int pram_conv2d_nhwc_f32(const float* in, int batch, int h, int w, in
     p.wo = (w + 2 * pad - ks) / stride + 1;
     p.m = batch * p.ho * p.wo;
     p.k = ks * ks * cin;
-    p.tiles_m = cdiv(p.m, gemm::BM);
-    p.tiles_n = cdiv(cout, gemm::BN);
-    dim3 grid(p.tiles_m * p.tiles_n), blk(gemm::NT);
-    if (cin == 4) hipLaunchKernelGGL(conv_kernel<true>, grid, blk, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(conv_kernel<false>, grid, blk, 0, (hipStream_t)stream, p);
+    int mi, wn;
+    gemm::choose_tile(p.m, cout, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(C4, MI_, WN_)                                                                                  \
+    do {                                                                                                      \
+        p.tiles_m = cdiv(p.m, gemm::Cfg<MI_, WN_>::BM);                                                       \
+        p.tiles_n = cdiv(cout, gemm::Cfg<MI_, WN_>::BN);                                                      \
+        hipLaunchKernelGGL((conv_kernel<C4, MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemm::NT), 0, st, p); \
+    } while (0)
+    if (cin == 4) { if (wn == 1) LAUNCH(true, 2, 1); else LAUNCH(true, 2, 2); }
+    else if (wn == 1) { if (mi == 2) LAUNCH(false, 2, 1); else LAUNCH(false, 1, 1); }
+    else { if (mi == 2) LAUNCH(false, 2, 2); else LAUNCH(false, 1, 2); }
+#undef LAUNCH
     return pram_launch_status("pram_conv2d_nhwc_f32");
 }
 

@@ -24,49 +24,64 @@
 
 namespace gemm {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = 36, NT = 256;
+constexpr int BK = 32, LDT = 36, NT = 256;
 
+// Tile geometry: 4 waves as WM x WN (WN = 2 or 1), each wave MI x 2 accumulators of 32 x 32:
+//   BM = WM * 32 * MI,  BN = WN * 64.   <2,2> = 128 x 128 (default), <1,2> = 64 x 128 (more, smaller
+//   workgroups when a 128-row grid cannot fill 2 x 256 CU slots), <2,1> = 256 x 64 and <1,1> = 128 x 64
+//   (64-channel outputs: conv1a / conv1b).
+template <int MI, int WN>
+struct Cfg {
+    static constexpr int WM = 4 / WN;
+    static constexpr int BM = WM * 32 * MI;
+    static constexpr int BN = WN * 64;
+    static constexpr int PA = BM / 32;   // float4 staging loads per thread for A
+    static constexpr int PB = BN / 32;   // ... for B
+};
+
+template <int MI, int WN>
 struct alignas(16) Smem {
-    float a[2][BM * LDT];
-    float b[2][BN * LDT];
-};  // 73,728 B -> two workgroups per CU
+    float a[2][Cfg<MI, WN>::BM * LDT];
+    float b[2][Cfg<MI, WN>::BN * LDT];
+};  // <2,2>: 73,728 B -> two workgroups per CU
 
-// Branch-free guarded float4 load: the address is always legal (clamped by the caller), the value is
-// zeroed when the element is out of range.  Branching around each load makes hipcc serialise them.
-__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
-    float4 v = *reinterpret_cast<const float4*>(p);
+// Guarded staging loads are branch-free and split in two: the loader returns the RAW float4 from an
+// always-legal (clamped) address, and a separate predicate says whether the element is in range.  The
+// zeroing select is applied only when the registers are written to LDS (after the MFMAs of the current
+// chunk), so nothing touches the loaded value — and no s_waitcnt vmcnt lands — before the matrix work.
+__device__ __forceinline__ float4 zero_unless(float4 v, bool ok) {
     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
 }
 
-// ALoad: float4 operator()(int row_in_tile_slot p (0..3), int kt) -> A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3]
-// BLoad: same for the weight rows.
-template <class ALoad, class BLoad>
-__device__ __forceinline__ void mainloop(Smem& s, ALoad& la, BLoad& lb, int nk, f32x16 (&acc)[2][2]) {
+// ALoad: float4 operator()(int p, int kt) -> raw A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3]; AOk: its predicate.
+// BLoad / BOk: same for the weight rows.
+template <int MI, int WN, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         f32x16 (&acc)[MI][2]) {
+    using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int srow = tid >> 3, skq = tid & 7;
 
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    float4 ra[4], rb[4];
+    float4 ra[C::PA], rb[C::PB];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        ra[p] = la(p, 0);
-        rb[p] = lb(p, 0);
-    }
+    for (int p = 0; p < C::PA; ++p) ra[p] = la(p, 0);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<float4*>(&s.a[0][(srow + 32 * p) * LDT + skq * 4]) = ra[p];
-        *reinterpret_cast<float4*>(&s.b[0][(srow + 32 * p) * LDT + skq * 4]) = rb[p];
-    }
+    for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, 0);
+#pragma unroll
+    for (int p = 0; p < C::PA; ++p) *reinterpret_cast<float4*>(&s.a[0][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, 0));
+#pragma unroll
+    for (int p = 0; p < C::PB; ++p) *reinterpret_cast<float4*>(&s.b[0][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, 0));
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -74,45 +89,71 @@ __device__ __forceinline__ void mainloop(Smem& s, ALoad& la, BLoad& lb, int nk, 
         const bool more = kt + 1 < nk;
         if (more) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ra[p] = la(p, kt + 1);
-                rb[p] = lb(p, kt + 1);
-            }
-        }
-        const float* sa = &s.a[cur][(wm * 64 + r) * LDT + h * 4];
-        const float* sb = &s.b[cur][(wn * 64 + r) * LDT + h * 4];
+            for (int p = 0; p < C::PA; ++p) ra[p] = la(p, kt + 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float4 af[2], bf[2];
-            af[0] = *reinterpret_cast<const float4*>(sa + kk * 8);
-            af[1] = *reinterpret_cast<const float4*>(sa + 32 * LDT + kk * 8);
-            bf[0] = *reinterpret_cast<const float4*>(sb + kk * 8);
-            bf[1] = *reinterpret_cast<const float4*>(sb + 32 * LDT + kk * 8);
-            const float a0[4] = {af[0].x, af[0].y, af[0].z, af[0].w};
-            const float a1[4] = {af[1].x, af[1].y, af[1].z, af[1].w};
-            const float b0[4] = {bf[0].x, bf[0].y, bf[0].z, bf[0].w};
-            const float b1[4] = {bf[1].x, bf[1].y, bf[1].z, bf[1].w};
+            for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, kt + 1);
+        }
+        const float* sa = &s.a[cur][(wm * 32 * MI + r) * LDT + h * 4];
+        const float* sb = &s.b[cur][(wn * 64 + r) * LDT + h * 4];
+        // fragments of sub-chunk kk+1 are read from LDS before the MFMAs of kk (pinned with sched_barrier:
+        // hipcc otherwise sinks every ds_read next to its first use and the wave eats the LDS latency)
+        float4 af[2][MI], bf[2][2];
+        auto fload = [&](int kk, float4 (&a)[MI], float4 (&b)[2]) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const float4*>(sa + mi * 32 * LDT + kk * 8);
+            b[0] = *reinterpret_cast<const float4*>(sb + kk * 8);
+            b[1] = *reinterpret_cast<const float4*>(sb + 32 * LDT + kk * 8);
+        };
+        auto fmma = [&](const float4 (&a)[MI], const float4 (&b)[2]) {
+            float av[MI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) { av[mi][0] = a[mi].x; av[mi][1] = a[mi].y; av[mi][2] = a[mi].z; av[mi][3] = a[mi].w; }
+            const float b0[4] = {b[0].x, b[0].y, b[0].z, b[0].w};
+            const float b1[4] = {b[1].x, b[1].y, b[1].z, b[1].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], b0[j], acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], b1[j], acc[mi][1], 0, 0, 0);
+                }
             }
-        }
+        };
+        fload(0, af[0], bf[0]);
+        fload(1, af[1], bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(af[0], bf[0]);
+        fload(2, af[0], bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(af[1], bf[1]);
+        fload(3, af[1], bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(af[0], bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(af[1], bf[1]);
         if (more) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *reinterpret_cast<float4*>(&s.a[cur ^ 1][(srow + 32 * p) * LDT + skq * 4]) = ra[p];
-                *reinterpret_cast<float4*>(&s.b[cur ^ 1][(srow + 32 * p) * LDT + skq * 4]) = rb[p];
-            }
+            for (int p = 0; p < C::PA; ++p)
+                *reinterpret_cast<float4*>(&s.a[cur ^ 1][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, kt + 1));
+#pragma unroll
+            for (int p = 0; p < C::PB; ++p)
+                *reinterpret_cast<float4*>(&s.b[cur ^ 1][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, kt + 1));
         }
         __syncthreads();
     }
 }
 
 // Accumulator element e of tile (mi, ni) of this lane lives at
-//   row = 64*wm + 32*mi + (e & 3) + 8*(e >> 2) + 4*h ,  col = 64*wn + 32*ni + (lane & 31)
+//   row = 32*MI*wm + 32*mi + (e & 3) + 8*(e >> 2) + 4*h ,  col = 64*wn + 32*ni + (lane & 31)
 __device__ __forceinline__ int acc_row(int mi, int e, int h) { return 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// Tile choice: 64-wide N tiles for <= 64 output channels; halve BM when the 128-row grid cannot put two
+// workgroups on every CU (the second co-resident workgroup is what hides barrier / epilogue time).
+inline void choose_tile(int m, int n, int* mi, int* wn) {
+    *wn = (n <= 64) ? 1 : 2;
+    const int bn = *wn * 64, bm2 = (4 / *wn) * 64;
+    const long blocks = (long)cdiv(m, bm2) * cdiv(n, bn);
+    *mi = (blocks < 2 * 256) ? 1 : 2;
+}
 
 }  // namespace gemm

@@ -21,9 +21,12 @@ struct LinArgs {
     int tiles_m, tiles_n;
 };
 
+template <int MI, int WN>
 __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
     using namespace gemm;
-    __shared__ Smem smem;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -44,20 +47,22 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
         const int rc = min(row, mlast), kc = min(k, klast);
         const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
         const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (a0 + (size_t)rc * p.lda0 + kc);
-        return ld4_or_zero(src, row < p.m && k < K);
+        return *reinterpret_cast<const float4*>(src);
     };
+    auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + 32 * pp) < p.m && (kt * BK + skq * 4) < K; };
     auto lb = [&](int pp, int kt) -> float4 {
         const int col = col0 + srow + 32 * pp;
         const int k = kt * BK + skq * 4;
-        return ld4_or_zero(w + (size_t)min(col, nlast) * K + min(k, klast), col < p.n && k < K);
+        return *reinterpret_cast<const float4*>(w + (size_t)min(col, nlast) * K + min(k, klast));
     };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.n && (kt * BK + skq * 4) < K; };
 
-    f32x16 acc[2][2];
-    mainloop(smem, la, lb, (K + BK - 1) / BK, acc);
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, la, oka, lb, okb, (K + BK - 1) / BK, acc);
 
     // ---- epilogue: all loads first (clamped addresses), then arithmetic, then predicated stores
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int cbase = col0 + wn * 64;
     const bool rot = (p.flags & PRAM_LIN_ROTARY) && cbase < p.rot_cols;
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
     const float b0 = p.bias ? p.bias[c0c] : 0.f, b1 = p.bias ? p.bias[c1c] : 0.f;
     const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int rbase = row0 + wm * 64;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int rbase = row0 + wm * 32 * MI;
         float rc_[16], rs_[16], q0[16], q1[16];
         if (rot) {
 #pragma unroll
@@ -177,6 +182,21 @@ __global__ void fourier_kernel(const float* __restrict__ kpts, const float* __re
     si[idx] = sinf(pr);
 }
 
+template <int MI, int WN>
+void launch_linear_t(LinArgs& p, int batch, hipStream_t st) {
+    using C = gemm::Cfg<MI, WN>;
+    p.tiles_m = cdiv(p.m, C::BM);
+    p.tiles_n = cdiv(p.n, C::BN);
+    hipLaunchKernelGGL((linear_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, batch), dim3(gemm::NT), 0, st, p);
+}
+
+void launch_linear(LinArgs& p, int batch, hipStream_t st) {
+    int mi, wn;
+    gemm::choose_tile(p.m * batch, p.n, &mi, &wn);
+    if (wn == 2) { if (mi == 2) launch_linear_t<2, 2>(p, batch, st); else launch_linear_t<1, 2>(p, batch, st); }
+    else         { if (mi == 2) launch_linear_t<2, 1>(p, batch, st); else launch_linear_t<1, 1>(p, batch, st); }
+}
+
 }  // namespace
 
 extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
@@ -191,8 +211,8 @@ extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a
         PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
     if (m == 0) return PRAM_OK;
     LinArgs p{a0, lda0, k0, a1, lda1, k1, w, bias, residual, ldr, out, ldo, m, n, alpha, flags,
-              rot_cos, rot_sin, rot_cols, 0, 0, 0, cdiv(m, gemm::BM), cdiv(n, gemm::BN)};
-    hipLaunchKernelGGL(linear_kernel, dim3(p.tiles_m * p.tiles_n, 1), dim3(gemm::NT), 0, (hipStream_t)stream, p);
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0};
+    launch_linear(p, 1, (hipStream_t)stream);
     return pram_launch_status("pram_linear_f32");
 }
 
@@ -203,8 +223,8 @@ extern "C" int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, co
     PRAM_REQUIRE(k % 4 == 0 && lda % 4 == 0 && ldb == k, "pram_bgemm_nt_f32: need k %% 4 == 0, lda %% 4 == 0, ldb == k");
     if (batch == 0 || m_max == 0 || n_max == 0) return PRAM_OK;
     LinArgs p{a, lda, k, nullptr, 0, 0, b, nullptr, nullptr, 0, c, ldc, m_max, n_max, alpha, 0,
-              nullptr, nullptr, 0, stride_a, stride_b, stride_c, cdiv(m_max, gemm::BM), cdiv(n_max, gemm::BN)};
-    hipLaunchKernelGGL(linear_kernel, dim3(p.tiles_m * p.tiles_n, batch), dim3(gemm::NT), 0, (hipStream_t)stream, p);
+              nullptr, nullptr, 0, stride_a, stride_b, stride_c, 0, 0};
+    launch_linear(p, batch, (hipStream_t)stream);
     return pram_launch_status("pram_bgemm_nt_f32");
 }
 
