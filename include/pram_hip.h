@@ -191,6 +191,40 @@ int pram_l2norm_rows_f32(float* x, int rows, int cols, void* stream);
 int pram_score_lookup_f32(const float* score_map, long long map_stride, int h, int w, const float* kpts,
                           const int* lens, int batch, int n_max, float* out, void* stream);
 
+/* ---------------------------------------------------------------- edges of the path ("next" rows) */
+
+/* F.interpolate(mode='bilinear', align_corners=True) on planar maps [planes][h][w] -> [planes][oh][ow]
+ * (score map of frames whose sides are not multiples of 8, nets/sfd2.py:301-303; multi-scale
+ * extraction nets/sfd2.py:412-415). */
+int pram_resize_bilinear_f32(const float* in, float* out, int planes, int h, int w, int oh, int ow,
+                             void* stream);
+
+/* Recogniser epilogue (Frame.add_segmentations, localization/frame.py:96-121): per token
+ * seg_scores = softmax(logits) (optional output), non_bg_mask = seg_scores[0] < bg_threshold,
+ * seg_ids = argmax(logits) - 1 (first occurrence), n_non_bg[b] = sum(non_bg_mask). */
+int pram_seg_epilogue_f32(const float* logits, const int* lens, int batch, int n_max, int n_class,
+                          float bg_threshold, float* seg_scores, int* seg_ids, int* non_bg_mask,
+                          int* n_non_bg, void* stream);
+
+/* torch.topk(x, k = cols, dim = -1) = full descending sort of each row (MultiMap3D.process_segmentations,
+ * localization/multimap3d.py:348-350); ties in canonical (value desc, index asc) order. cols <= 1024. */
+int pram_row_sort_desc_f32(const float* x, int ld, int rows, int cols, float* vals, long long* idx,
+                           void* stream);
+
+/* Row top-2 of a batched matrix (largest = 1: sim.topk(2), nearest_neighbor.py:5-17; largest = 0:
+ * topk(largest=False), singlemap3d.py:428).  v0/v1 best and second best values, i0 index of the best
+ * (lowest index on ties).  x [batch][m_max][ld]. */
+int pram_row_top2_f32(const float* x, int ld, long long stride, const int* row_lens, const int* col_lens,
+                      int batch, int m_max, int n_max, int largest, float* v0, float* v1, long long* i0,
+                      void* stream);
+
+/* Projection-refinement matching (SingleMap3D.refine_pose_by_projection, singlemap3d.py:416-433):
+ * dist[i][j] = sqrt(2 - 2*sim[i][j] + 1e-6) + (||kpts[i] - proj_uv[:, j]|| >= range ? 100 : 0); per query
+ * row the two smallest distances d0 <= d1 and the index of d0.  sim [m][ld] (= q_descs @ ref_descs^T),
+ * kpts [m][2], proj_uv [2][n] (u row then v row). */
+int pram_proj_dist_top2_f32(const float* sim, int ld, const float* kpts, const float* proj_uv, int m, int n,
+                            float range, float* d0, float* d1, long long* i0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

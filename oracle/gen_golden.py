@@ -304,6 +304,119 @@ def gen_sfd2(ref):
         save(f"nms_crafted_r{rad}", score=sm.numpy(), nms=a.numpy(), radius=rad)
 
 
+def _stub_missing_modules():
+    """MagicMock stand-ins (harness only) for modules the reference imports at module scope but that the
+    pinned functions never touch: pycolmap, cv2, h5py, ...."""
+    import importlib
+    from unittest import mock
+    for name in ['pycolmap', 'cv2', 'h5py', 'open3d', 'pypangolin', 'tensorboardX', 'matplotlib', 'matplotlib.pyplot',
+                 'sklearn', 'sklearn.cluster', 'skimage', 'skimage.io', 'tqdm']:
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = mock.MagicMock()
+
+
+def gen_edges(ref):
+    """recogniser epilogue, NearestNeighbor matcher, projection matching, offline extraction."""
+    print("edges of the path")
+    _stub_missing_modules()
+    import localization.frame as ref_frame
+    import localization.multimap3d as ref_mm
+    import localization.matchers.nearest_neighbor as ref_nn
+    # ---- NearestNeighbor (mutual / ratio / distance)
+    pair = W.synthetic_match_pair(7, 300, 260)
+    d0, d1 = pair["descriptors0"].t()[None].contiguous(), pair["descriptors1"].t()[None].contiguous()
+    arrs = {}
+    for tag, conf in {"mutual": {}, "ratio": {"ratio_threshold": 0.9, "do_mutual_check": False},
+                      "dist": {"distance_threshold": 0.7}}.items():
+        model = ref_nn.NearestNeighbor(conf).eval()
+        with torch.no_grad():
+            r = model({"descriptors0": d0, "descriptors1": d1})
+        o = R.nn_forward(d0, d1, **{k: v for k, v in {**ref_nn.NearestNeighbor.default_conf, **conf}.items()})
+        assert torch.equal(r["matches0"], o["matches0"]) and maxdiff(r["matching_scores0"], o["matching_scores0"]) < 1e-6, tag
+        arrs[f"m0_{tag}"] = r["matches0"].numpy().astype(np.int32)
+        arrs[f"s0_{tag}"] = r["matching_scores0"].numpy()
+        print(f"  NN {tag}: {(r['matches0'] >= 0).sum().item()} matches")
+    save("nn_m300_n260", **arrs)
+    # ---- recogniser epilogue on oracle logits
+    sd = W.make_state_dict("segnetvit", ref["load"].load_segnet("segnetvit", 113, 256, 15, 1024).state_dict(), seed=7)
+    desc, kp, _ = W.synthetic_tokens(3, 400)
+    with torch.no_grad():
+        logits = R.segnetvit_forward(sd, desc[None], kp[None], (1, 3, 480, 640))[0]
+    logits[:, 0] += 6.0   # make background competitive so the 0.95 filter has something to do
+    fr = ref_frame.Frame.__new__(ref_frame.Frame)
+    fr.keypoints = np.zeros((400, 3))
+    fr.descriptors = np.zeros((400, 128))
+    fr.initialize_localization_variables = lambda: None
+    import io, contextlib
+    for thr, tag in ((0.95, "thr095"), (0.2, "thr02"), (0.0, "thr0")):
+        fr.keypoints = np.arange(400 * 3, dtype=float).reshape(400, 3)
+        fr.descriptors = np.zeros((400, 128))
+        with contextlib.redirect_stdout(io.StringIO()):
+            fr.add_segmentations(logits.clone(), thr)
+        o = R.add_segmentations(logits.clone(), thr)
+        kept_ref = (fr.keypoints[:, 0] / 3).astype(int)
+        kept_or = np.arange(400) if o["keep"] is None else np.nonzero(o["keep"].numpy())[0]
+        assert np.array_equal(kept_ref, kept_or), tag
+        assert np.array_equal(fr.seg_ids, o["seg_ids"].numpy()) and np.abs(fr.seg_scores - o["seg_scores"].numpy()).max() < 1e-7
+        print(f"  add_segmentations thr={thr}: kept {len(kept_ref)}/400, distinct ids {len(np.unique(fr.seg_ids))}")
+        arrs = dict(kept=kept_ref.astype(np.int32), seg_ids=fr.seg_ids.astype(np.int32), seg_scores_sub=fr.seg_scores[:, ::8])
+        if tag == "thr095":
+            with contextlib.redirect_stdout(io.StringIO()):
+                ps_ref = ref_mm.MultiMap3D.process_segmentations(None, torch.from_numpy(fr.seg_scores), topk=20)
+            ps_or = R.process_segmentations(torch.from_numpy(fr.seg_scores), topk=20)
+            assert len(ps_ref) == len(ps_or)
+            for a, b in zip(ps_ref, ps_or):
+                assert a[0] == b[0] and np.array_equal(a[1], b[1]) and abs(a[2] - b[2]) < 1e-7
+            arrs["ps_sids"] = np.array([a[0] for a in ps_ref], dtype=np.int32)
+            arrs["ps_counts"] = np.array([len(a[1]) for a in ps_ref], dtype=np.int32)
+            arrs["ps_scores"] = np.array([a[2] for a in ps_ref], dtype=np.float64)
+            print(f"  process_segmentations: top sids {arrs['ps_sids'][:6].tolist()} counts {arrs['ps_counts'][:6].tolist()}")
+        save(f"segpost_{tag}", **arrs)
+    np.savez_compressed(OUT / "segpost_logits.npz", logits=logits.numpy())
+    # ---- projection matching (restated from singlemap3d.py:416-433; pinned against the inline reference expressions)
+    pair = W.synthetic_match_pair(9, 500, 700)
+    q_k, q_d, r_d = pair["keypoints0"], pair["descriptors0"], pair["descriptors1"]
+    uv = (pair["keypoints1"] + W.normal(9, "proj/jitter", (700, 2), 3.0)).t().contiguous()
+    thr = 8.0
+    pe = torch.sqrt(torch.sum((q_k[..., None] - uv[:2][None]) ** 2, dim=1))
+    dd = torch.sqrt(2 - 2 * q_d @ r_d.t() + 1e-6)
+    dd[pe >= 2 * thr] = dd[pe >= 2 * thr] + 100
+    dists, ids = torch.topk(dd, k=2, largest=False, dim=1)
+    rmask = ((dists[:, 0] / dists[:, 1]) <= 0.995) * (dists[:, 0] < 100)
+    om, oi, od = R.match_by_projection(q_k, q_d, uv, r_d, thr)
+    assert torch.equal(rmask, om) and torch.equal(ids[:, 0][rmask], oi[rmask]) and maxdiff(dists, od) < 1e-6
+    print(f"  match_by_projection: {int(rmask.sum())}/500 pass the ratio test")
+    save("projmatch_m500_n700", ratio_mask=rmask.numpy(), ids=ids[:, 0].numpy().astype(np.int32), dists=dists.numpy(),
+         uv=uv.numpy(), threshold=thr)
+    # ---- offline extraction (extract_sfd2_return); harness shim: .cuda() is the identity on this CPU-only box
+    s = ref["sfd2"]
+    net = s.ResNet4x(3, 128).eval()
+    sd2 = W.make_state_dict("sfd2", net.state_dict(), seed=7)
+    net.load_state_dict(sd2, strict=True)
+    raw = W.uniform(77, "offline/img", (1, 3, 96, 128), 0.0, 1.0) * 0.5 + 0.5 * torch.nn.functional.interpolate(
+        W.uniform(77, "offline/coarse", (1, 3, 7, 9), 0.0, 1.0), size=(96, 128), mode="bilinear", align_corners=True)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, kw in {"s1": dict(conf_th=0.001, topK=100), "ms": dict(conf_th=0.001, topK=150, scales=[1.0, 0.75])}.items():
+            r = s.extract_sfd2_return(net, raw.clone(), **kw)
+            o = R.extract_sfd2_return(sd2, raw.clone(), **kw)
+            # canonicalise the reference's unstable argsort among equal scores
+            def canon(d):
+                key = np.lexsort((d["keypoints"][:, 0], d["keypoints"][:, 1], -d["scores"]))
+                return d["keypoints"][key], d["scores"][key], d["descriptors"][key]
+            rk, rs, rd = canon(r)
+            ok_, os_, od_ = canon(o)
+            assert np.array_equal(rk, ok_) and np.abs(rs - os_).max() < 1e-7 and np.abs(rd - od_).max() < 1e-5, tag
+            print(f"  extract_sfd2_return {tag}: {len(rk)} keypoints")
+            save(f"sfd2_offline_{tag}", keypoints=rk, scores=rs, descriptors_sub=rd[:, ::8], **{k: np.array(v) for k, v in kw.items()})
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
 def gen_schema(ref):
     """State-dict key/shape schema of the reference modules (what load_state_dict(strict=True) needs)."""
     print("state-dict schema")
@@ -326,7 +439,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
-    only = sys.argv[1:] or ["schema", "normalize", "sinkhorn", "segnetvit", "gml", "adagml", "sfd2"]
+    only = sys.argv[1:] or ["schema", "normalize", "sinkhorn", "segnetvit", "gml", "adagml", "sfd2", "edges"]
     for name in only:
         globals()[f"gen_{name}"](ref)
     print("all reference-vs-oracle checks passed; fixtures written to", OUT)

@@ -447,3 +447,128 @@ def sfd2_sample(score_map: torch.Tensor, semi_descs: torch.Tensor, kpts: torch.T
     d = sample_descriptors(kpts, semi_descs, s, norm_desc)
     sc = score_map[0, kpts[:, 1].long(), kpts[:, 0].long()]
     return sc, d
+
+
+# ------------------------------------------------------------------------------------------
+# Edges of the path — recogniser epilogue, NN matcher, projection matching,
+# offline extraction.  Same status: test infrastructure, pinned by oracle/gen_golden.py.
+# ------------------------------------------------------------------------------------------
+def _top2(x: torch.Tensor, largest: bool):
+    """top-2 per row with the canonical tie rule (lowest index first); torch.topk's order among ties is unspecified."""
+    order = torch.sort(x, dim=-1, descending=largest, stable=True)
+    return order.values[..., :2], order.indices[..., :2]
+
+
+def nn_find_nn(sim: torch.Tensor, ratio_thresh, distance_thresh):
+    """localization/matchers/nearest_neighbor.py:5-17"""
+    sim_nn, ind_nn = _top2(sim, True)
+    if not ratio_thresh:
+        sim_nn, ind_nn = sim_nn[..., :1], ind_nn[..., :1]
+    dist_nn = 2 * (1 - sim_nn)
+    mask = torch.ones(ind_nn.shape[:-1], dtype=torch.bool)
+    if ratio_thresh:
+        mask = mask & (dist_nn[..., 0] <= (ratio_thresh ** 2) * dist_nn[..., 1])
+    if distance_thresh:
+        mask = mask & (dist_nn[..., 0] <= distance_thresh ** 2)
+    matches = torch.where(mask, ind_nn[..., 0], ind_nn.new_tensor(-1))
+    scores = torch.where(mask, (sim_nn[..., 0] + 1) / 2, sim_nn.new_tensor(0))
+    return matches, scores
+
+
+def nn_forward(desc0: torch.Tensor, desc1: torch.Tensor, ratio_threshold=None, distance_threshold=None,
+               do_mutual_check=True) -> dict:
+    """NearestNeighbor._forward — nearest_neighbor.py:39-56; descriptors [B, D, N]."""
+    sim = torch.einsum('bdn,bdm->bnm', desc0, desc1)
+    m0, s0 = nn_find_nn(sim, ratio_threshold, distance_threshold)
+    if do_mutual_check:
+        m1, _ = nn_find_nn(sim.transpose(1, 2), ratio_threshold, distance_threshold)
+        inds0 = torch.arange(m0.shape[-1])
+        loop = torch.gather(m1, -1, torch.where(m0 > -1, m0, m0.new_tensor(0)))
+        m0 = torch.where((m0 > -1) & (inds0 == loop), m0, m0.new_tensor(-1))
+    return {'matches0': m0, 'matching_scores0': s0}
+
+
+def add_segmentations(segmentations: torch.Tensor, filtering_threshold: float) -> dict:
+    """Frame.add_segmentations — localization/frame.py:96-121 (the keypoint/descriptor filtering is returned as 'keep')."""
+    seg_scores = torch.softmax(segmentations, dim=-1)
+    keep = None
+    if filtering_threshold > 0:
+        non_bg = seg_scores[:, 0] < filtering_threshold
+        if torch.sum(non_bg) >= 0.4 * seg_scores.shape[0]:
+            keep = non_bg
+            segmentations, seg_scores = segmentations[non_bg], seg_scores[non_bg]
+    return {'keep': keep, 'segmentations': segmentations, 'seg_scores': seg_scores,
+            'seg_ids': segmentations.max(dim=-1)[1] - 1}
+
+
+def process_segmentations(segs: torch.Tensor, topk: int = 10):
+    """MultiMap3D.process_segmentations — localization/multimap3d.py:348-379; full sort in canonical tie order."""
+    order = torch.sort(segs, dim=-1, descending=True, stable=True)
+    pred_values, pred_ids = order.values.numpy(), order.indices.numpy()
+    out, used = [], []
+    for k in range(segs.shape[-1]):
+        values_k, ids_k = pred_values[:, k], pred_ids[:, k]
+        out_k = []
+        for sid in np.unique(ids_k):
+            if sid == 0 or sid in used:
+                continue
+            used.append(sid)
+            ids = np.where(ids_k == sid)[0]
+            out_k.append((ids.shape[0], sid, ids, np.mean(values_k[ids])))
+        for v in sorted(out_k, key=lambda item: item[0], reverse=True):
+            out.append((v[1], v[2], v[3]))
+            if len(out) >= topk:
+                return out
+    return out
+
+
+def match_by_projection(q_kpts, q_descs, proj_uvs, ref_descs, threshold: float):
+    """Descriptor matching inside SingleMap3D.refine_pose_by_projection — localization/singlemap3d.py:416-433."""
+    proj_error = q_kpts[:, :2][..., None] - proj_uvs[:2][None]
+    proj_error = torch.sqrt(torch.sum(proj_error ** 2, dim=1))
+    out_of_range = proj_error >= 2 * threshold
+    desc_dist = torch.sqrt(2 - 2 * q_descs @ ref_descs.t() + 1e-6)
+    desc_dist[out_of_range] = desc_dist[out_of_range] + 100
+    dists, ids = _top2(desc_dist, False)
+    ratios = dists[:, 0] / dists[:, 1]
+    return (ratios <= 0.995) & (dists[:, 0] < 100), ids[:, 0], dists
+
+
+def extract_sfd2_return(sd: SD, img: torch.Tensor, conf_th=0.001, topK=-1, scales=(1.0,)):
+    """extract_sfd2_return — nets/sfd2.py:386-589 (mask=None path).  img [1,3,H,W] in [0,1], un-normalised."""
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    img = ((img.squeeze() - mean) / std)[None]
+    _, _, H, W = img.shape
+    all_pts, all_descs = [], []
+    for s in scales:
+        new_img = img if s == 1.0 else F.interpolate(img, size=(int(H * s), int(W * s)), mode='bilinear', align_corners=True)
+        nh, nw = new_img.shape[2:]
+        bb = sfd2_backbone(sd, new_img)
+        heat = score_map_from_logits(bb["logits"])
+        desc_map = F.normalize(bb["desc_raw"], dim=1)
+        if heat.shape[1] != nh or heat.shape[2] != nw:
+            heat = F.interpolate(heat[:, None], size=[nh, nw], mode='bilinear', align_corners=True)[:, 0]
+        sc_map = simple_nms(heat, 3)[0]
+        yx = torch.nonzero(sc_map > conf_th)
+        sc = sc_map[yx[:, 0], yx[:, 1]]
+        order = torch.sort(sc, descending=True, stable=True).indices
+        yx, sc = yx[order], sc[order]
+        x, y = yx[:, 1], yx[:, 0]
+        keep = ~((x < 4) | (x >= W - 4) | (y < 4) | (y >= H - 4))
+        x, y, sc = x[keep], y[keep], sc[keep]
+        if x.numel() == 0:
+            continue
+        grid = torch.stack([x.float() / (float(nw) / 2.) - 1., y.float() / (float(nh) / 2.) - 1.], -1).view(1, 1, -1, 2)
+        d = F.grid_sample(desc_map, grid, mode='bilinear', align_corners=True).reshape(desc_map.shape[1], -1).numpy()
+        d = d / np.linalg.norm(d, axis=0)[np.newaxis, :]
+        all_pts.append(torch.stack([x.float() * W / nw, y.float() * H / nh, sc], 1).numpy())
+        all_descs.append(d.T)
+    if not all_pts:
+        return None, None, None
+    pts, descs = np.vstack(all_pts), np.vstack(all_descs)
+    kp, scs = pts[:, :2], pts[:, 2]
+    if topK > 0:
+        idx = np.argsort(-np.array(scs, dtype=float), kind="stable")[:topK]
+        kp, scs, descs = kp[idx], scs[idx], descs[idx]
+    return {"keypoints": np.array(kp, dtype=float), "descriptors": np.array(descs, dtype=float), "scores": np.array(scs, dtype=float)}

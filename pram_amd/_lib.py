@@ -41,6 +41,11 @@ _SIGS = {
     "pram_select_keypoints_f32": (I, [P, I, I, I, F, I, I, I, I, P, P, P, P, P]),
     "pram_sample_nhwc_f32": (I, [P, I, I, I, I, P, P, I, I, I, P, P]),
     "pram_l2norm_rows_f32": (I, [P, I, I, P]),
+    "pram_resize_bilinear_f32": (I, [P, P, I, I, I, I, I, P]),
+    "pram_seg_epilogue_f32": (I, [P, P, I, I, I, F, P, P, P, P, P]),
+    "pram_row_sort_desc_f32": (I, [P, I, I, I, P, P, P]),
+    "pram_row_top2_f32": (I, [P, I, LL, P, P, I, I, I, I, P, P, P, P]),
+    "pram_proj_dist_top2_f32": (I, [P, I, P, P, I, I, F, P, P, P, P]),
     "pram_score_lookup_f32": (I, [P, LL, I, I, P, P, I, I, P, P]),
 }
 

@@ -1,0 +1,229 @@
+// Kernels at the edges of the hot path: bilinear resize (score map of non-multiple-of-8 frames,
+// multi-scale extraction), generic grid_sample, the recogniser epilogue (softmax / background filter /
+// argmax, localization/frame.py:96-121), full descending row sort (torch.topk(k=C),
+// localization/multimap3d.py:348-350) and row top-2 (nearest-neighbour matching,
+// localization/matchers/nearest_neighbor.py:5-17; projection refinement singlemap3d.py:428-433).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// F.interpolate(mode='bilinear', align_corners=True) on planar maps [planes][h][w] -> [planes][oh][ow]
+// (ATen upsample_bilinear2d arithmetic: src = dst * (in-1)/(out-1), lambda = src - floor(src)).
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w,
+                                       int oh, int ow, float rh, float rw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)planes * oh * ow;
+    if (i >= total) return;
+    const int ox = (int)(i % ow);
+    const long long t = i / ow;
+    const int oy = (int)(t % oh);
+    const int pl = (int)(t / oh);
+    const float h1r = rh * (float)oy;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < h - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float w1r = rw * (float)ox;
+    const int w1 = (int)w1r;
+    const int w1p = (w1 < w - 1) ? 1 : 0;
+    const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    const float* p = in + (size_t)pl * h * w + (size_t)h1 * w + w1;
+    out[i] = h0l * (w0l * p[0] + w1l * p[w1p]) + h1l * (w0l * p[(size_t)h1p * w] + w1l * p[(size_t)h1p * w + w1p]);
+}
+
+// ---- recogniser epilogue: one wave per token -------------------------------------------------------
+// seg_scores = softmax(logits); non_bg = scores[0] < thr; seg_id = argmax(logits) - 1 (first occurrence)
+__global__ __launch_bounds__(256) void seg_epilogue_kernel(const float* __restrict__ logits, const int* __restrict__ lens,
+                                                           int n_max, int c, float thr, float* __restrict__ scores_out,
+                                                           int* __restrict__ seg_id, int* __restrict__ non_bg,
+                                                           int* __restrict__ n_non_bg) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int len = lens ? lens[b] : n_max;
+    if (n >= len) return;
+    const float* x = logits + ((size_t)b * n_max + n) * c;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = lane; j < c; j += 64) {
+        const float v = x[j];
+        if (v > mx) { mx = v; mi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    float sum = 0.f;
+    for (int j = lane; j < c; j += 64) sum += expf(x[j] - mx);
+    sum = wave_sum(sum);
+    if (scores_out) {
+        float* so = scores_out + ((size_t)b * n_max + n) * c;
+        for (int j = lane; j < c; j += 64) so[j] = expf(x[j] - mx) / sum;
+    }
+    if (lane == 0) {
+        const float bg = expf(x[0] - mx) / sum;
+        const int keep = bg < thr;
+        seg_id[(size_t)b * n_max + n] = mi - 1;
+        non_bg[(size_t)b * n_max + n] = keep;
+        if (keep) atomicAdd(&n_non_bg[b], 1);
+    }
+}
+
+// ---- full descending sort of each row (value desc, index asc): bitonic in LDS, one workgroup per row
+constexpr int SORT_MAX = 1024;
+__global__ __launch_bounds__(256) void row_sort_kernel(const float* __restrict__ x, int ld, int c, float* __restrict__ vals,
+                                                       long long* __restrict__ idx) {
+    __shared__ unsigned long long keys[SORT_MAX];
+    const int row = blockIdx.x;
+    int p2 = 1;
+    while (p2 < c) p2 <<= 1;
+    for (int j = threadIdx.x; j < p2; j += 256) {
+        unsigned long long k = 0ull;     // pads sort last
+        if (j < c) {
+            unsigned u = __float_as_uint(x[(size_t)row * ld + j]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving float -> uint
+            k = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+            if (k == 0ull) k = 1ull;
+        }
+        keys[j] = k;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= p2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < p2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], bb = keys[ixj];
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? (a < bb) : (a > bb)) { keys[i] = bb; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int j = threadIdx.x; j < c; j += 256) {
+        const unsigned long long k = keys[j];
+        unsigned u = (unsigned)(k >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        vals[(size_t)row * c + j] = __uint_as_float(u);
+        idx[(size_t)row * c + j] = (long long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    }
+}
+
+// ---- row top-2 (largest or smallest), one wave per row; ties -> lowest index ---------------------------
+__global__ __launch_bounds__(256) void row_top2_kernel(const float* __restrict__ x, int ld, long long stride,
+                                                       const int* __restrict__ row_lens, const int* __restrict__ col_lens,
+                                                       int m_max, int n_max, int largest, float* __restrict__ v0,
+                                                       float* __restrict__ v1, long long* __restrict__ i0) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = row_lens ? row_lens[b] : m_max, n = col_lens ? col_lens[b] : n_max;
+    if (row >= m) return;
+    const float* p = x + b * stride + (size_t)row * ld;
+    const float sgn = largest ? 1.f : -1.f;
+    float a0 = -INFINITY, a1 = -INFINITY;     // top-1 / top-2 of sgn * x
+    int j0 = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const float v = sgn * p[j];
+        if (v > a0) { a1 = a0; a0 = v; j0 = j; }
+        else if (v > a1) a1 = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float b0 = __shfl_xor(a0, o, 64), b1 = __shfl_xor(a1, o, 64);
+        const int k0 = __shfl_xor(j0, o, 64);
+        if (b0 > a0 || (b0 == a0 && k0 < j0)) { a1 = fmaxf(a0, b1); a0 = b0; j0 = k0; }
+        else a1 = fmaxf(a1, b0);
+    }
+    if (lane == 0) {
+        v0[(size_t)b * m_max + row] = sgn * a0;
+        if (v1) v1[(size_t)b * m_max + row] = sgn * a1;
+        i0[(size_t)b * m_max + row] = (n > 0) ? j0 : -1;
+    }
+}
+
+// ---- projection refinement matching (SingleMap3D.refine_pose_by_projection, singlemap3d.py:416-433) ----
+// dist[i][j] = sqrt(2 - 2 sim[i][j] + 1e-6) + (||kpt_i - uv_j|| >= 2*thr ? 100 : 0); row top-2 smallest.
+__global__ __launch_bounds__(256) void proj_top2_kernel(const float* __restrict__ sim, int ld, const float* __restrict__ kpts,
+                                                        const float* __restrict__ uv, int m, int n, float range,
+                                                        float* __restrict__ d0, float* __restrict__ d1,
+                                                        long long* __restrict__ i0) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const float kx = kpts[row * 2], ky = kpts[row * 2 + 1];
+    const float* p = sim + (size_t)row * ld;
+    float a0 = INFINITY, a1 = INFINITY;
+    int j0 = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const float ex = kx - uv[j], ey = ky - uv[n + j];
+        const float pe = sqrtf(ex * ex + ey * ey);
+        float v = sqrtf((2.f - 2.f * p[j]) + 1e-6f);
+        if (pe >= range) v = v + 100.f;
+        if (v < a0) { a1 = a0; a0 = v; j0 = j; }
+        else if (v < a1) a1 = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float b0 = __shfl_xor(a0, o, 64), b1 = __shfl_xor(a1, o, 64);
+        const int k0 = __shfl_xor(j0, o, 64);
+        if (b0 < a0 || (b0 == a0 && k0 < j0)) { a1 = fminf(a0, b1); a0 = b0; j0 = k0; }
+        else a1 = fminf(a1, b0);
+    }
+    if (lane == 0) { d0[row] = a0; d1[row] = a1; i0[row] = (n > 0) ? j0 : -1; }
+}
+
+}  // namespace
+
+extern "C" int pram_proj_dist_top2_f32(const float* sim, int ld, const float* kpts, const float* proj_uv, int m, int n,
+                                       float range, float* d0, float* d1, long long* i0, void* stream) {
+    PRAM_REQUIRE(sim && kpts && proj_uv && d0 && d1 && i0, "pram_proj_dist_top2_f32: null pointer");
+    if (m == 0) return PRAM_OK;
+    hipLaunchKernelGGL(proj_top2_kernel, dim3(cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, sim, ld, kpts, proj_uv, m, n, range,
+                       d0, d1, i0);
+    return pram_launch_status("pram_proj_dist_top2_f32");
+}
+
+extern "C" int pram_resize_bilinear_f32(const float* in, float* out, int planes, int h, int w, int oh, int ow, void* stream) {
+    PRAM_REQUIRE(in && out && h > 0 && w > 0 && oh > 0 && ow > 0, "pram_resize_bilinear_f32: bad arguments");
+    if (planes == 0) return PRAM_OK;
+    const float rh = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
+    const float rw = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    const long long total = (long long)planes * oh * ow;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       planes, h, w, oh, ow, rh, rw);
+    return pram_launch_status("pram_resize_bilinear_f32");
+}
+
+extern "C" int pram_seg_epilogue_f32(const float* logits, const int* lens, int batch, int n_max, int n_class, float bg_threshold,
+                                     float* seg_scores, int* seg_ids, int* non_bg_mask, int* n_non_bg, void* stream) {
+    PRAM_REQUIRE(logits && seg_ids && non_bg_mask && n_non_bg && n_class > 0, "pram_seg_epilogue_f32: bad arguments");
+    if (batch == 0 || n_max == 0) return PRAM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(n_non_bg, 0, (size_t)batch * 4, st) != hipSuccess) {
+        pram_set_error("pram_seg_epilogue_f32: memset failed");
+        return PRAM_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(seg_epilogue_kernel, dim3(cdiv(n_max, 4), batch), dim3(256), 0, st, logits, lens, n_max, n_class,
+                       bg_threshold, seg_scores, seg_ids, non_bg_mask, n_non_bg);
+    return pram_launch_status("pram_seg_epilogue_f32");
+}
+
+extern "C" int pram_row_sort_desc_f32(const float* x, int ld, int rows, int cols, float* vals, long long* idx, void* stream) {
+    PRAM_REQUIRE(x && vals && idx, "pram_row_sort_desc_f32: null pointer");
+    PRAM_REQUIRE(cols > 0 && cols <= SORT_MAX, "pram_row_sort_desc_f32: cols=%d not in (0, %d]", cols, SORT_MAX);
+    if (rows == 0) return PRAM_OK;
+    hipLaunchKernelGGL(row_sort_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, cols, vals, idx);
+    return pram_launch_status("pram_row_sort_desc_f32");
+}
+
+extern "C" int pram_row_top2_f32(const float* x, int ld, long long stride, const int* row_lens, const int* col_lens, int batch,
+                                 int m_max, int n_max, int largest, float* v0, float* v1, long long* i0, void* stream) {
+    PRAM_REQUIRE(x && v0 && i0, "pram_row_top2_f32: null pointer");
+    if (batch == 0 || m_max == 0) return PRAM_OK;
+    hipLaunchKernelGGL(row_top2_kernel, dim3(cdiv(m_max, 4), batch), dim3(256), 0, (hipStream_t)stream, x, ld, stride, row_lens,
+                       col_lens, m_max, n_max, largest, v0, v1, i0);
+    return pram_launch_status("pram_row_top2_f32");
+}

@@ -286,15 +286,19 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ f
     const int len = lens ? lens[b] : n_max;
     if (n >= len) return;
     const float kx = kpts[((size_t)b * n_max + n) * 2], ky = kpts[((size_t)b * n_max + n) * 2 + 1];
-    // sample_descriptors: k = k - s/2 + 0.5 ; k /= (w*s - s/2 - 0.5, h*s - s/2 - 0.5) ; k = k*2 - 1
-    const float half = s * 0.5f;
-    const float dx = (float)fw * s - half - 0.5f, dy = (float)fh * s - half - 0.5f;
-    float gx = (kx - half) + 0.5f;
-    float gy = (ky - half) + 0.5f;
-    gx = gx / dx;
-    gy = gy / dy;
-    gx = gx * 2.f - 1.f;
-    gy = gy * 2.f - 1.f;
+    // s > 0: sample_descriptors map  k = k - s/2 + 0.5 ; k /= (w*s - s/2 - 0.5, h*s - s/2 - 0.5) ; k = k*2 - 1
+    // s <= 0: kpts are already normalised grid coordinates in [-1, 1] (plain F.grid_sample)
+    float gx = kx, gy = ky;
+    if (s > 0.f) {
+        const float half = s * 0.5f;
+        const float dx = (float)fw * s - half - 0.5f, dy = (float)fh * s - half - 0.5f;
+        gx = (kx - half) + 0.5f;
+        gy = (ky - half) + 0.5f;
+        gx = gx / dx;
+        gy = gy / dy;
+        gx = gx * 2.f - 1.f;
+        gy = gy * 2.f - 1.f;
+    }
     // grid_sampler_compute_source_index, align_corners=True: ((g + 1) / 2) * (size - 1)
     const float ix = ((gx + 1.f) / 2.f) * (float)(fw - 1);
     const float iy = ((gy + 1.f) / 2.f) * (float)(fh - 1);

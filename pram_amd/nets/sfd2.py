@@ -159,11 +159,10 @@ class ResNet4x(blk.PackedCache, nn.Module):
         padded keypoints [B,k,2], scores [B,k], descriptors [B,k,128], counts int32 [B] (device)."""
         cfg = {**self.default_config, **config}
         b, _, ih, iw = image.shape
-        if ih % 8 or iw % 8:
-            raise NotImplementedError("image sides must be multiples of 8 (the bilinear score resize of "
-                                      "nets/sfd2.py:301-303 is not implemented on the GPU path)")
         P, o1b, o2b, o3b, o4 = self._backbone(image)
         _, score = self._score_head(P, o4)
+        if score.shape[1] != ih or score.shape[2] != iw:      # nets/sfd2.py:301-303
+            score = ops.resize_bilinear(score, ih, iw)
         nms = ops.simple_nms(score, 4)
         if cfg['max_keypoints'] < 0:
             raise NotImplementedError("max_keypoints < 0 (keep all) is not supported; pass a bound")
@@ -218,6 +217,58 @@ def load_sfd2(weight_path):
     return net
 
 
-def extract_sfd2_return(*args, **kwargs):
-    raise NotImplementedError("extract_sfd2_return (offline multi-scale extraction, nets/sfd2.py:386-589) is the "
-                              "offline-mapping variant and not on the per-query path; see DESIGN.md")
+@torch.no_grad()
+def extract_sfd2_return(model, img, conf_th=0.001, mask=None, topK=-1, min_keypoints=0, **kwargs):
+    """Offline extraction variant (nets/sfd2.py:386-589): det() per scale, NMS radius 3, ``>`` threshold,
+    sort by score, border 4, descriptors at the keypoints, float64 numpy outputs.  The dense work (convs,
+    NMS, resize, descriptor sampling) runs in HIP; the per-keypoint bookkeeping is the reference's numpy.
+    Ties in the score sort follow (score desc, row-major index asc) — numpy's argsort order among equal
+    scores is unspecified in the reference."""
+    import numpy as np
+    dev = next(model.parameters()).device
+    img = norm_RGB(img.squeeze())[None].to(dev).float()
+    B, one, H, W = img.shape
+    all_pts, all_descs = [], []
+    for s in kwargs.get('scales', [1.0]):
+        if s == 1.0:
+            new_img = img
+        else:
+            nh, nw = int(H * s), int(W * s)
+            new_img = ops.resize_bilinear(img, nh, nw)
+        nh, nw = new_img.shape[2:]
+        heatmap, coarse_desc = model.det(new_img)
+        if heatmap.size(1) != nh or heatmap.size(2) != nw:
+            heatmap = ops.resize_bilinear(heatmap, nh, nw)
+        scores = ops.simple_nms(heatmap, 3)[0]
+        yx = torch.nonzero(scores > conf_th)
+        sc = scores[yx[:, 0], yx[:, 1]]
+        order = torch.sort(sc, descending=True, stable=True).indices
+        yx, sc = yx[order], sc[order]
+        x, y = yx[:, 1], yx[:, 0]
+        keep = ~((x < 4) | (x >= W - 4) | (y < 4) | (y >= H - 4))     # NB: reference tests against the ORIGINAL W, H
+        x, y, sc = x[keep], y[keep], sc[keep]
+        if x.numel() == 0:
+            continue
+        D = coarse_desc.size(1)
+        if coarse_desc.size(2) == nh and coarse_desc.size(3) == nw:
+            desc = coarse_desc[0, :, y, x]
+        else:
+            grid = torch.stack([x.float() / (float(nw) / 2.) - 1., y.float() / (float(nh) / 2.) - 1.], -1)[None]
+            nhwc = coarse_desc.permute(0, 2, 3, 1)
+            nhwc = nhwc if nhwc.is_contiguous() else nhwc.contiguous()
+            desc = ops.sample_nhwc(nhwc, grid, None, 0, False)[0].t()
+            desc = desc / torch.linalg.norm(desc, dim=0, keepdim=True)
+        pts = torch.stack([x.float() * W / nw, y.float() * H / nh, sc], 1).cpu().numpy()
+        all_pts.append(pts)
+        all_descs.append(desc.t().cpu().numpy())
+    if not all_pts:
+        return None, None, None
+    all_pts, all_descs = np.vstack(all_pts), np.vstack(all_descs)
+    keypoints, scores, descriptors = all_pts[:, 0:2], all_pts[:, 2], all_descs
+    if mask is not None:
+        raise NotImplementedError("mask-labelled extraction (nets/sfd2.py:508-571) belongs to offline map building")
+    if topK > 0:
+        idxes = np.argsort(-np.array(scores, dtype=float), kind="stable")[:topK]
+        keypoints, scores, descriptors = keypoints[idxes], scores[idxes], descriptors[idxes]
+    return {"keypoints": np.array(keypoints, dtype=float), "descriptors": np.array(descriptors, dtype=float),
+            "scores": np.array(scores, dtype=float)}

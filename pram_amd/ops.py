@@ -323,3 +323,70 @@ def score_lookup(score_map_: torch.Tensor, kpts: torch.Tensor, lens: Optional[to
     _lib.check(L.pram_score_lookup_f32(_p(score_map_), stride, H, W, _p(kpts), _p(lens), Bk, N, _p(out), _st()),
                "pram_score_lookup_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------- edges of the path
+def resize_bilinear(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
+    """F.interpolate(x, size=(oh, ow), mode='bilinear', align_corners=True) for [..., h, w] planar maps."""
+    L = _lib.load()
+    x = x.contiguous().float()
+    _chk(x, "x")
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    out = torch.empty(*x.shape[:-2], oh, ow, device=x.device, dtype=torch.float32)
+    _lib.check(L.pram_resize_bilinear_f32(_p(x), _p(out), planes, h, w, int(oh), int(ow), _st()), "pram_resize_bilinear_f32")
+    return out
+
+
+def seg_epilogue(logits: torch.Tensor, lens: Optional[torch.Tensor], bg_threshold: float, want_scores: bool = False):
+    """logits [B,N,C] -> seg_ids int32 [B,N], non_bg_mask int32 [B,N], n_non_bg int32 [B], seg_scores or None."""
+    L = _lib.load()
+    logits = logits.contiguous()
+    _chk(logits, "logits")
+    B, N, Cc = logits.shape
+    ids = torch.full((B, N), -2, device=logits.device, dtype=torch.int32)
+    mask = torch.zeros(B, N, device=logits.device, dtype=torch.int32)
+    cnt = torch.zeros(B, device=logits.device, dtype=torch.int32)
+    sc = torch.zeros_like(logits) if want_scores else None
+    _lib.check(L.pram_seg_epilogue_f32(_p(logits), _p(lens), B, N, Cc, float(bg_threshold), _p(sc), _p(ids), _p(mask), _p(cnt), _st()),
+               "pram_seg_epilogue_f32")
+    return ids, mask, cnt, sc
+
+
+def row_sort_desc(x: torch.Tensor):
+    L = _lib.load()
+    x = x.contiguous()
+    rows, cols = _rows2d(x, "x")
+    vals = torch.empty_like(x)
+    idx = torch.empty(x.shape, device=x.device, dtype=_INT64)
+    _lib.check(L.pram_row_sort_desc_f32(_p(x), cols, rows, cols, _p(vals), _p(idx), _st()), "pram_row_sort_desc_f32")
+    return vals, idx
+
+
+def row_top2(x: torch.Tensor, largest: bool, n_valid: Optional[int] = None, row_lens=None, col_lens=None):
+    """x [B,M,ld] -> (best [B,M], second [B,M], index of best int64 [B,M])"""
+    L = _lib.load()
+    assert x.is_contiguous() and x.dim() == 3
+    B, M, ld = x.shape
+    N = n_valid or ld
+    v0 = torch.zeros(B, M, device=x.device, dtype=torch.float32)
+    v1 = torch.zeros(B, M, device=x.device, dtype=torch.float32)
+    i0 = torch.full((B, M), -1, device=x.device, dtype=_INT64)
+    _lib.check(L.pram_row_top2_f32(_p(x), ld, M * ld, _p(row_lens), _p(col_lens), B, M, N, int(largest), _p(v0), _p(v1), _p(i0), _st()),
+               "pram_row_top2_f32")
+    return v0, v1, i0
+
+
+def proj_dist_top2(sim: torch.Tensor, kpts: torch.Tensor, proj_uv: torch.Tensor, rng: float, n_valid: Optional[int] = None):
+    """sim [M, ld] fp32, kpts [M,2], proj_uv [2,N] -> (d0 [M], d1 [M], i0 int64 [M])"""
+    L = _lib.load()
+    assert sim.is_contiguous() and sim.dim() == 2
+    M, ld = sim.shape
+    N = n_valid or ld
+    kpts, proj_uv = kpts.contiguous().float(), proj_uv.contiguous().float()
+    d0 = torch.zeros(M, device=sim.device, dtype=torch.float32)
+    d1 = torch.zeros(M, device=sim.device, dtype=torch.float32)
+    i0 = torch.full((M,), -1, device=sim.device, dtype=_INT64)
+    _lib.check(L.pram_proj_dist_top2_f32(_p(sim), ld, _p(kpts), _p(proj_uv), M, N, float(rng), _p(d0), _p(d1), _p(i0), _st()),
+               "pram_proj_dist_top2_f32")
+    return d0, d1, i0

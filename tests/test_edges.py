@@ -1,0 +1,152 @@
+"""SURVEY.md §8(f) rows (recogniser epilogue, NearestNeighbor matcher, projection matching) and the offline
+extraction variant a6: oracle vs golden on CPU, HIP vs golden/oracle on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from pram_amd import weights as W
+from tests import helpers as H
+
+
+def _nn_inputs():
+    pair = W.synthetic_match_pair(7, 300, 260)
+    return pair["descriptors0"].t()[None].contiguous(), pair["descriptors1"].t()[None].contiguous()
+
+
+NN_CONFS = {"mutual": {}, "ratio": {"ratio_threshold": 0.9, "do_mutual_check": False}, "dist": {"distance_threshold": 0.7}}
+
+
+def _proj_inputs():
+    pair = W.synthetic_match_pair(9, 500, 700)
+    return pair["keypoints0"], pair["descriptors0"], pair["descriptors1"]
+
+
+def _offline_image():
+    return W.uniform(77, "offline/img", (1, 3, 96, 128), 0.0, 1.0) * 0.5 + 0.5 * torch.nn.functional.interpolate(
+        W.uniform(77, "offline/coarse", (1, 3, 7, 9), 0.0, 1.0), size=(96, 128), mode="bilinear", align_corners=True)
+
+
+def _canon(d):
+    key = np.lexsort((d["keypoints"][:, 0], d["keypoints"][:, 1], -d["scores"]))
+    return d["keypoints"][key], d["scores"][key], d["descriptors"][key]
+
+
+# ------------------------------------------------------------------ CPU: oracle vs golden
+def test_oracle_nn(golden):
+    g = golden("nn_m300_n260")
+    d0, d1 = _nn_inputs()
+    for tag, conf in NN_CONFS.items():
+        o = R.nn_forward(d0, d1, **{"ratio_threshold": None, "distance_threshold": None, "do_mutual_check": True, **conf})
+        assert np.array_equal(o["matches0"].numpy(), g[f"m0_{tag}"]) and np.abs(o["matching_scores0"].numpy() - g[f"s0_{tag}"]).max() < 1e-6
+
+
+def test_oracle_segpost(golden):
+    logits = torch.from_numpy(golden("segpost_logits")["logits"])
+    for thr, tag in ((0.95, "thr095"), (0.2, "thr02"), (0.0, "thr0")):
+        g = golden(f"segpost_{tag}")
+        o = R.add_segmentations(logits.clone(), thr)
+        kept = np.arange(400) if o["keep"] is None else np.nonzero(o["keep"].numpy())[0]
+        assert np.array_equal(kept, g["kept"]) and np.array_equal(o["seg_ids"].numpy(), g["seg_ids"])
+        if tag == "thr095":
+            ps = R.process_segmentations(o["seg_scores"], topk=20)
+            assert [p[0] for p in ps] == g["ps_sids"].tolist() and [len(p[1]) for p in ps] == g["ps_counts"].tolist()
+
+
+def test_oracle_projection_and_offline(golden):
+    g = golden("projmatch_m500_n700")
+    qk, qd, rd = _proj_inputs()
+    m, i, d = R.match_by_projection(qk, qd, torch.from_numpy(g["uv"]), rd, float(g["threshold"]))
+    assert np.array_equal(m.numpy(), g["ratio_mask"]) and np.array_equal(i.numpy()[g["ratio_mask"]], g["ids"][g["ratio_mask"]])
+    for tag in ("s1", "ms"):
+        g = golden(f"sfd2_offline_{tag}")
+        kw = dict(conf_th=float(g["conf_th"]), topK=int(g["topK"]))
+        if "scales" in g.files:
+            kw["scales"] = g["scales"].tolist()
+        k, s, dsc = _canon(R.extract_sfd2_return(H.sfd2_sd(), _offline_image(), **kw))
+        assert np.array_equal(k, g["keypoints"]) and np.abs(s - g["scores"]).max() < 1e-7
+        assert np.abs(dsc[:, ::8] - g["descriptors_sub"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ GPU: HIP vs golden
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_hip_nearest_neighbor(dev, golden):
+    import pram_amd.localization.matchers as matchers
+    from pram_amd.localization.base_model import dynamic_load
+    g = golden("nn_m300_n260")
+    d0, d1 = _nn_inputs()
+    for tag, conf in NN_CONFS.items():
+        model = dynamic_load(matchers, "nearest_neighbor")(conf).eval()
+        r = model({"descriptors0": d0.to(dev), "descriptors1": d1.to(dev)})
+        assert np.array_equal(r["matches0"].cpu().numpy(), g[f"m0_{tag}"]), tag
+        assert np.abs(r["matching_scores0"].cpu().numpy() - g[f"s0_{tag}"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_recogniser_epilogue(dev, golden):
+    from pram_amd.localization import recognition_post as P
+    logits = torch.from_numpy(golden("segpost_logits")["logits"]).to(dev)
+    for thr, tag in ((0.95, "thr095"), (0.2, "thr02"), (0.0, "thr0")):
+        g = golden(f"segpost_{tag}")
+        r = P.add_segmentations(logits.clone(), thr)
+        kept = np.arange(400) if r["keep"] is None else np.nonzero(r["keep"].cpu().numpy())[0]
+        assert np.array_equal(kept, g["kept"]) and np.array_equal(r["seg_ids"].cpu().numpy(), g["seg_ids"])
+        assert np.abs(r["seg_scores"][:, ::8].cpu().numpy() - g["seg_scores_sub"]).max() < 1e-6
+        if tag == "thr095":
+            ps = P.process_segmentations(r["seg_scores"], topk=20)
+            assert [int(p[0]) for p in ps] == g["ps_sids"].tolist() and [len(p[1]) for p in ps] == g["ps_counts"].tolist()
+            assert np.abs(np.array([p[2] for p in ps]) - g["ps_scores"]).max() < 1e-6
+    # full sort == torch.sort (stable, descending) incl. exact ties and negative values
+    from pram_amd import ops
+    x = torch.floor(W.normal(31, "sort/x", (37, 161), 3.0))
+    v, i = ops.row_sort_desc(x.to(dev))
+    o = torch.sort(x, dim=-1, descending=True, stable=True)
+    assert torch.equal(v.cpu(), o.values) and torch.equal(i.cpu(), o.indices)
+
+
+@pytest.mark.gpu
+def test_hip_projection_matching(dev, golden):
+    from pram_amd.localization import recognition_post as P
+    g = golden("projmatch_m500_n700")
+    qk, qd, rd = _proj_inputs()
+    m, i, d = P.match_by_projection(qk.to(dev), qd.to(dev), torch.from_numpy(g["uv"]).to(dev), rd.to(dev), float(g["threshold"]))
+    assert np.array_equal(m.cpu().numpy(), g["ratio_mask"])
+    assert np.array_equal(i.cpu().numpy()[g["ratio_mask"]], g["ids"][g["ratio_mask"]])
+    assert np.abs(d.cpu().numpy() - g["dists"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_offline_extraction_and_odd_sizes(dev, golden):
+    from pram_amd import ops
+    from pram_amd.nets.sfd2 import ResNet4x, extract_sfd2_return
+    net = ResNet4x()
+    net.load_state_dict(H.sfd2_sd(), strict=True)
+    net = net.to(dev).eval()
+    for tag in ("s1", "ms"):
+        g = golden(f"sfd2_offline_{tag}")
+        kw = dict(conf_th=float(g["conf_th"]), topK=int(g["topK"]))
+        if "scales" in g.files:
+            kw["scales"] = g["scales"].tolist()
+        k, s, dsc = _canon(extract_sfd2_return(net, _offline_image(), **kw))
+        same = {tuple(x) for x in k} & {tuple(x) for x in g["keypoints"]}
+        print(f"offline {tag}: {len(same)}/{len(g['keypoints'])} keypoints identical")
+        assert len(same) >= 0.95 * len(g["keypoints"])
+        if len(same) == len(k):
+            assert np.abs(s - g["scores"]).max() < 1e-5 and np.abs(dsc[:, ::8] - g["descriptors_sub"]).max() < 1e-3
+    # bilinear resize == F.interpolate(align_corners=True)
+    x = W.uniform(5, "rs/x", (2, 3, 37, 53), 0.0, 1.0)
+    ref = torch.nn.functional.interpolate(x, size=(50, 41), mode="bilinear", align_corners=True)
+    assert H.maxdiff(ops.resize_bilinear(x.to(dev), 50, 41), ref) < 1e-6
+    # a frame whose sides are not multiples of 8 (score map resize of nets/sfd2.py:301-303)
+    img = W.synthetic_image(3, 100, 132)[None]
+    o = R.sfd2_extract_local_global(H.sfd2_sd(), img, max_keypoints=64, min_keypoints=8)
+    r = net.extract_local_global({"image": img.to(dev)}, {"max_keypoints": 64, "min_keypoints": 8})
+    assert tuple(r["score_map"].shape) == (1, 100, 132) and H.maxdiff(r["score_map"], o["score_map"]) < 1e-5
+    same = (r["keypoints"][0].cpu()[:, None, :] == o["keypoints"][0][None]).all(-1).any(1).float().mean().item()
+    assert same > 0.9
