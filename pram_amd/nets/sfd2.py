@@ -258,7 +258,11 @@ def extract_sfd2_return(model, img, conf_th=0.001, mask=None, topK=-1, min_keypo
             nhwc = nhwc if nhwc.is_contiguous() else nhwc.contiguous()
             desc = ops.sample_nhwc(nhwc, grid, None, 0, False)[0].t()
             desc = desc / torch.linalg.norm(desc, dim=0, keepdim=True)
-        pts = torch.stack([x.float() * W / nw, y.float() * H / nh, sc], 1).cpu().numpy()
+        # rescale on the host in numpy float32 like the reference (sfd2.py:483-484): torch's GPU division by a
+        # scalar multiplies by the reciprocal and lands 1 ulp away from the correctly rounded quotient
+        pts = torch.stack([x.float(), y.float(), sc], 1).cpu().numpy()
+        pts[:, 0] = pts[:, 0] * W / nw
+        pts[:, 1] = pts[:, 1] * H / nh
         all_pts.append(pts)
         all_descs.append(desc.t().cpu().numpy())
     if not all_pts:

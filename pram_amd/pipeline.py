@@ -18,8 +18,9 @@ from . import ops
 
 
 class QueryPipeline:
-    def __init__(self, sfd2, segnet, matcher, max_keypoints: int = 2048, min_keypoints: int = 128):
+    def __init__(self, sfd2, segnet, matcher, max_keypoints: int = 2048, min_keypoints: int = 128, bg_threshold: float = 0.95):
         self.sfd2, self.segnet, self.matcher = sfd2, segnet, matcher
+        self.bg_threshold = bg_threshold
         self.cfg = {'min_keypoints': min_keypoints, 'max_keypoints': max_keypoints}
 
     @torch.no_grad()
@@ -35,7 +36,10 @@ class QueryPipeline:
             _, seg = self.sfd2.sample_batched(ex['score_map'], ex['mid_features'], kpts, counts, norm_desc=False)
             pred = self.segnet({'seg_descriptors': seg, 'keypoints': kpts, 'image': images, 'lens': counts})['prediction']
             out['prediction'] = pred
-            out['landmark'] = ops.row_argmax(pred) if hasattr(ops, 'row_argmax') else None
+            # recogniser epilogue (Frame.add_segmentations, frame.py:96-121): landmark id = argmax - 1,
+            # background mask at the reference's pre_filtering_th (configs/config_train_7scenes_sfd2.yaml:98)
+            ids, non_bg, n_non_bg, _ = ops.seg_epilogue(pred, counts, self.bg_threshold)
+            out['landmark'], out['non_bg'], out['n_non_bg'] = ids, non_bg, n_non_bg
         if 'm' in stages and ref is not None:
             data = {
                 'descriptors0': ex['descriptors'], 'keypoints0': kpts, 'scores0': scores, 'lens0': counts,
