@@ -199,8 +199,12 @@ def main():
     step()
     torch.cuda.synchronize()
     probe, ops.attention_probe = ops.attention_probe, None
-    attn_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in probe)
-    attn_flops = sum(f for f, _, _ in probe)
+    attn_ms, attn_flops = 0.0, 0.0
+    for ql, kl, mm, nn, hh, bb, e0, e1 in probe:
+        attn_ms += e0.elapsed_time(e1)
+        qv = ql.double() if ql is not None else torch.full((bb,), float(mm), dtype=torch.float64, device=dev)
+        kv = kl.double() if kl is not None else torch.full((bb,), float(nn), dtype=torch.float64, device=dev)
+        attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic = None
     try:   # HBM bytes per attention launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.md)

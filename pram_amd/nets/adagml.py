@@ -1,10 +1,11 @@
 """AdaGML — adaptive GML (per-layer confidence pooling, token pruning, early exit) on the HIP kernels.
 
 Same config, state-dict schema and ``produce_matches`` output as the reference
-(nets/adagml.py:232-404): ``matches0`` / ``matching_scores0`` scattered back to the full query set,
-B = 1 semantics (the reference's mask indexing drops the batch dimension; a batch of pairs is run
-pair by pair).  The per-layer stop test needs one 3-int device->host read, exactly where the
-reference's Python ``if`` synchronises.
+(nets/adagml.py:232-404): ``matches0`` / ``matching_scores0`` scattered back to the full query set.
+The reference is B = 1 only (its mask indexing drops the batch dimension) and its Python ``if``
+synchronises with the device every layer; here a batch of pairs runs in one device-resident pass with
+per-pair token counts / stop flags kept in device tensors (no host read), each pair computing exactly
+its B = 1 result.  An emptied token set yields "no matches" instead of the reference's IndexError.
 """
 from __future__ import annotations
 
@@ -89,61 +90,81 @@ class AdaGML(GML):
 
     @torch.no_grad()
     def produce_matches(self, data: dict, p: float = 0.2, **kwargs):
+        """Batched, device-resident AdaGML (nets/adagml.py:307-404 per pair).  All nI layers are enqueued;
+        per-pair state (token counts, survivor ids, stop flag, the matching descriptors of the layer the
+        pair stopped at) lives in device tensors and is committed with masked selects, so the early exit of
+        the reference's Python loop costs no device->host read.  A pair that has stopped gets token count 0
+        for the remaining layers (its attention workgroups exit immediately)."""
         desc0, desc1 = data['descriptors0'], data['descriptors1']
         blk.require_cuda(desc0, "AdaGML.produce_matches")
         _ = data['scores0'], data['scores1']     # read like the reference (KeyError if absent), unused in compute
-        if desc0.shape[0] != 1:
-            outs = [self.produce_matches({k: (v[i:i + 1] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == desc0.shape[0]
-                                              and not k.startswith('image') else v) for k, v in data.items()}, p=p)
-                    for i in range(desc0.shape[0])]
-            return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         probes = kwargs.get('probes')
         (k0, cx0, cy0, sc0), (k1, cx1, cy1, sc1) = normalize_inputs(data)
         P = self._packed_get(self._build_packed)
-        m, n = desc0.shape[1], desc1.shape[1]
+        B, m, _ = desc0.shape
+        n = desc1.shape[1]
         T = max(m, n)
         dev = desc0.device
-        X = torch.zeros(2, T, desc0.shape[2], device=dev, dtype=torch.float32)
-        X[0, :m], X[1, :n] = desc0[0], desc1[0]
-        cos = torch.zeros(2, T, 32, device=dev, dtype=torch.float32)
-        sin = torch.zeros(2, T, 32, device=dev, dtype=torch.float32)
+        X = torch.zeros(2 * B, T, desc0.shape[2], device=dev, dtype=torch.float32)
+        X[:B, :m], X[B:, :n] = desc0, desc1
+        cos = torch.zeros(2 * B, T, 32, device=dev, dtype=torch.float32)
+        sin = torch.zeros(2 * B, T, 32, device=dev, dtype=torch.float32)
         c0, s0 = ops.fourier_encoding(k0.float(), P["Wr"], cx0, cy0, sc0)
         c1, s1 = ops.fourier_encoding(k1.float(), P["Wr"], cx1, cy1, sc1)
-        cos[0, :m], sin[0, :m], cos[1, :n], sin[1, :n] = c0[0], s0[0], c1[0], s1[0]
-        ind = torch.zeros(2, T, device=dev, dtype=torch.int32)
-        ind[0, :m] = torch.arange(m, device=dev, dtype=torch.int32)
-        ind[1, :n] = torch.arange(n, device=dev, dtype=torch.int32)
-        lens = torch.tensor([m, n], device=dev, dtype=torch.int32)
-        x = ops.linear(X.view(2 * T, -1), P["in_w"], P["in_b"])
+        cos[:B, :m], sin[:B, :m], cos[B:, :n], sin[B:, :n] = c0, s0, c1, s1
+        ind = torch.zeros(2 * B, T, device=dev, dtype=torch.int32)
+        ind[:B, :m] = torch.arange(m, device=dev, dtype=torch.int32)
+        ind[B:, :n] = torch.arange(n, device=dev, dtype=torch.int32)
+        l0 = data.get('lens0')
+        l1 = data.get('lens1')
+        lens = torch.cat([l0.int() if l0 is not None else torch.full((B,), m, device=dev, dtype=torch.int32),
+                          l1.int() if l1 is not None else torch.full((B,), n, device=dev, dtype=torch.int32)]).contiguous()
+        num_points = (lens[:B] + lens[B:]).float()            # m + n of the ORIGINAL sets (adagml.py:370)
+        active = torch.ones(B, device=dev, dtype=torch.bool)
+        stop_layer = torch.full((B,), -1, device=dev, dtype=torch.int32)
+        d = self.config['hidden_dim']
+        md_final = torch.zeros(2 * B, T, d, device=dev, dtype=torch.float32)
+        lens_final = lens.clone()
+        ind_final = ind.clone()
+        x = ops.linear(X.view(2 * B * T, -1), P["in_w"], P["in_b"])
         nI = self.n_layers
-        ni = 0
         for ni in range(nI):
-            x, col_self = blk.self_block(x, P["self"][ni], cos.view(-1, 32), sin.view(-1, 32), 2, T, lens, want_colmean=True)
-            x, col0, col1 = blk.cross_block(x, P["cross"][ni], 1, T, lens, want_colmean=True)
-            score4 = torch.zeros(2, T, 4, device=dev, dtype=torch.float32)
+            lens_eff = torch.where(active.repeat(2), lens, torch.zeros_like(lens)).contiguous()
+            x, col_self = blk.self_block(x, P["self"][ni], cos.view(-1, 32), sin.view(-1, 32), 2 * B, T, lens_eff, want_colmean=True)
+            x, col0, col1 = blk.cross_block(x, P["cross"][ni], B, T, lens_eff, want_colmean=True)
+            score4 = torch.zeros(2 * B, T, 4, device=dev, dtype=torch.float32)
             score4[:, :, 0] = col_self
-            score4[0, :, 1], score4[1, :, 1] = col0[0], col1[0]
-            logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * T, 4)).view(2, T)
+            score4[:B, :, 1], score4[B:, :, 1] = col0, col1
+            logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * B * T, 4)).view(2 * B, T)
             if ni >= 1:
                 thr = self.confidence_threshold(ni)
                 x3, cos, sin, ind, lens_new, n_below, conf = ops.adagml_prune(
-                    logit, thr, self.n_min_tokens, lens, x.view(2, T, -1), cos, sin, ind, want_conf=probes is not None)
-                x = x3.view(2 * T, -1)
-                lens = lens_new
+                    logit, thr, self.n_min_tokens, lens_eff, x.view(2 * B, T, -1), cos, sin, ind, want_conf=probes is not None)
+                x = x3.view(2 * B * T, -1)
+                lens = torch.where(active.repeat(2), lens_new, lens)
                 if probes is not None:
                     probes[f"conf_{ni}"] = conf
-                below = int(n_below.sum().item())     # host sync: the reference's `if self.check_if_stop(...)`
-                if 1.0 - below / float(m + n) > 0.95:
-                    break
+                # check_if_stop (adagml.py:522-531): 1 - #(conf < thr) / (m + n) > 0.95, same fp32 arithmetic
+                below = (n_below[:B] + n_below[B:]).float()
+                stop_now = active & ((1.0 - below / num_points) > 0.95)
+                if ni == nI - 1:
+                    stop_now = active.clone()              # loop exhausted: use the last layer (adagml.py:374)
+                md = ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25).view(2 * B, T, d)
+                sel = stop_now.repeat(2)
+                md_final = torch.where(sel[:, None, None], md, md_final)
+                lens_final = torch.where(sel, lens, lens_final)
+                ind_final = torch.where(sel[:, None], ind, ind_final)
+                stop_layer = torch.where(stop_now, torch.full_like(stop_layer, ni), stop_layer)
+                active = active & ~stop_now
             elif probes is not None:
                 probes[f"conf_{ni}"] = torch.sigmoid(logit)
-        d = x.shape[-1]
-        md = ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25).view(2, T, d)
         ldc = (T + 3) // 4 * 4
-        dist = ops.bgemm_nt(md[:1], md[1:], ldc=ldc)
-        r = ops.sinkhorn_match(dist, P["bin"], self.sinkhorn_iterations, p, m_lens=lens[:1], n_lens=lens[1:],
+        dist = ops.bgemm_nt(md_final[:B].contiguous(), md_final[B:].contiguous(), ldc=ldc)
+        lf0, lf1 = lens_final[:B].contiguous(), lens_final[B:].contiguous()
+        r = ops.sinkhorn_match(dist, P["bin"], self.sinkhorn_iterations, p, m_lens=lf0, n_lens=lf1,
                                dual_softmax=not self.with_sinkhorn, n_valid=T)
-        out_m, out_s = ops.adagml_scatter(r['matches0'], r['matching_scores0'], ind[0:1], ind[1:2], lens[:1], m)
+        out_m, out_s = ops.adagml_scatter(r['matches0'], r['matching_scores0'], ind_final[:B].contiguous(),
+                                          ind_final[B:].contiguous(), lf0, m)
         if probes is not None:
-            probes.update(stop_layer=ni, ind=ind, lens=lens)
+            probes.update(stop_layer=stop_layer, ind=ind_final, lens=lens_final)
         return {'matches0': out_m, 'matching_scores0': out_s}

@@ -126,8 +126,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
                "pram_attention_f32")
     if probe is not None:
         e1.record()
-        # algorithmic FLOPs of QK^T + PV at the padded sizes: 4 * m * n * 64 per (batch, head)
-        probe.append((4.0 * m_max * n_max * 64 * heads * batch, e0, e1))
+        # algorithmic FLOPs of QK^T + PV: 4 * m_b * n_b * 64 per (batch element, head), from the ACTUAL ragged
+        # lengths (device tensors, summed by the caller after synchronising)
+        probe.append((q_lens, k_lens, m_max, n_max, heads, batch, e0, e1))
     return (out, lse) if want_lse else out
 
 

@@ -160,11 +160,52 @@ def test_adagml_golden(dev, golden, tag):
     lens = probes["lens"].tolist()
     ind0 = probes["ind"][0, :lens[0]].cpu().numpy()
     ind1 = probes["ind"][1, :lens[1]].cpu().numpy()
-    print(f"adagml {tag}: stop {probes['stop_layer']} (golden {int(g['stop_layer'])}), survivors {lens} (golden {len(g['ind0'])}, {len(g['ind1'])})")
-    assert probes["stop_layer"] == int(g["stop_layer"])
+    stop = int(probes["stop_layer"][0].item())
+    print(f"adagml {tag}: stop {stop} (golden {int(g['stop_layer'])}), survivors {lens} (golden {len(g['ind0'])}, {len(g['ind1'])})")
+    assert stop == int(g["stop_layer"])
     assert np.array_equal(ind0, g["ind0"]) and np.array_equal(ind1, g["ind1"])
     assert np.array_equal(r["matches0"].cpu().numpy(), g["m0_p0"])
     assert np.abs(r["matching_scores0"].cpu().numpy() - g["s0"]).max() < 1e-3
+
+
+def test_adagml_early_stop_vs_oracle(dev):
+    """pooling biases shifted so that the pair clears check_if_stop before the last layer: stop layer, survivor ids
+    and matches against the (reference-pinned) oracle."""
+    from pram_amd.nets.adagml import AdaGML
+    sd = dict(H.adagml_sd())
+    for k in list(sd):
+        if k.endswith("predict.3.bias"):
+            sd[k] = sd[k] + 0.08
+    net = AdaGML({})
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    data, _ = H.pair_data(4, 600, 520)
+    po = {}
+    o = R.adagml_produce_matches(sd, data, p=0.0, probes=po)
+    pg = {}
+    r = net.produce_matches({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}, p=0.0, probes=pg)
+    print(f"adagml early stop: oracle layer {po['stop_layer']} sizes {po['sizes']}, hip layer {int(pg['stop_layer'][0])}")
+    assert po["stop_layer"] < 8, "fixture should stop early"
+    assert int(pg["stop_layer"][0]) == po["stop_layer"]
+    lens = pg["lens"].tolist()
+    assert torch.equal(pg["ind"][0, :lens[0]].cpu().long(), po["ind0"]) and torch.equal(pg["ind"][1, :lens[1]].cpu().long(), po["ind1"])
+    assert torch.equal(r["matches0"].cpu(), o["matches0"])
+    assert H.maxdiff(r["matching_scores0"], o["matching_scores0"]) < 1e-3
+
+
+def test_adagml_batch_equals_single(dev):
+    """B = 3 pairs of different difficulty in one device-resident call == three B = 1 calls (stop layers differ)."""
+    net = _adagml(dev)
+    ds = [H.pair_data(i, 448, 448, device=dev)[0] for i in (1, 2, 3)]
+    cat = {k: torch.cat([d[k] for d in ds], 0) for k in ds[0] if torch.is_tensor(ds[0][k])}
+    cat["image_shape0"] = cat["image_shape1"] = (1, 3, 640, 480)
+    pb = {}
+    rb = net.produce_matches(cat, p=0.0, probes=pb)
+    for i, d in enumerate(ds):
+        p1 = {}
+        r1 = net.produce_matches(d, p=0.0, probes=p1)
+        assert int(pb["stop_layer"][i]) == int(p1["stop_layer"][0])
+        assert torch.equal(rb["matches0"][i], r1["matches0"][0]) and torch.equal(rb["matching_scores0"][i], r1["matching_scores0"][0])
 
 
 def _sfd2(dev):
