@@ -29,13 +29,13 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64
 H, W_IMG = 480, 640
 
 
-def build_models(dev, matcher_name):
+def build_models(dev, matcher_name, n_class=113):
     from pram_amd import weights as W
     from pram_amd.nets.adagml import AdaGML
     from pram_amd.nets.gml import GML
     from pram_amd.nets.load_segnet import load_segnet
     from pram_amd.nets.sfd2 import ResNet4x
-    sfd2, seg = ResNet4x(), load_segnet('segnetvit', 113, 256, 15, 1024)
+    sfd2, seg = ResNet4x(), load_segnet('segnetvit', n_class, 256, 15, 1024)
     matcher = GML({}) if matcher_name == "gml" else AdaGML({})
     sds = {}
     for name, m in (("sfd2", sfd2), ("segnetvit", seg), (matcher_name, matcher)):
@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-per-gpu", type=int, default=8, help="queries per GPU per step (C3: 64 over 8 GPUs)")
     ap.add_argument("--kpts", type=int, default=2048)
+    ap.add_argument("--n-class", type=int, default=113, help="landmark classes (7Scenes 113, Cambridge 161, Aachen 513)")
     ap.add_argument("--matcher", default="gml", choices=["gml", "adagml"])
     ap.add_argument("--stages", default="erm", help="e=extract r=recognise m=match")
     ap.add_argument("--cpu-queries", type=int, default=4, help="CPU-baseline sample size (0 = skip)")
@@ -157,7 +158,7 @@ def main():
 
     from pram_amd import ops, weights as Wt
     from pram_amd.pipeline import QueryPipeline, gather_records
-    sfd2, seg, matcher, sds = build_models(dev, args.matcher)
+    sfd2, seg, matcher, sds = build_models(dev, args.matcher, args.n_class)
     pipe = QueryPipeline(sfd2, seg, matcher, max_keypoints=args.kpts, min_keypoints=128)
 
     B = args.batch_per_gpu
@@ -207,10 +208,11 @@ def main():
         attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic = None
-    try:   # HBM bytes per attention launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.md)
-        traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    if (args.kpts, B, args.matcher, args.stages, args.n_class) == (2048, 8, "gml", "erm", 113):
+        try:   # HBM bytes per attention launch of THIS configuration, from the committed rocprofv3 --pmc passes
+            traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
     roofline = {"bound": "mfma", "kernel": "attention_kernel (f32 MFMA flash attention)", "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(attn_flops / max(1, len(probe)) / 512.0), "launches_per_step": len(probe), "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
@@ -219,10 +221,10 @@ def main():
     if rank == 0:
         total_q = world * B * args.steps
         line = {
-            "metric": "query images/sec (640x480, 2048 kpts, 7Scenes nc113)", "value": round(total_q / dt, 3), "unit": "queries/s",
+            "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})", "value": round(total_q / dt, 3), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"7Scenes full hot path: SFD2 extract+sample -> SegNetViT nc113 (15 layers) -> "
+            "config": {"workload": f"{'7Scenes' if args.n_class == 113 else 'custom'} full hot path: SFD2 extract+sample -> SegNetViT nc{args.n_class} (15 layers) -> "
                                    f"{args.matcher.upper()} match + 20 Sinkhorn iters vs a {args.kpts}-kpt reference set; "
                                    f"stages={args.stages}",
                        "queries_per_gpu_per_step": B, "frame": f"{W_IMG}x{H}", "keypoints": args.kpts,

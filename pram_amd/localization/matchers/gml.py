@@ -1,27 +1,13 @@
-"""Matcher plugin 'gml' (reference: localization/matchers/gml.py:13-45)."""
-import torch
-
+"""Matcher plugin 'gml' — same construction / checkpoint / forward contract as the reference's
+localization/matchers/gml.py:13-45, network = pram_amd.nets.gml.GML on the HIP kernels."""
 from pram_amd.localization.base_model import BaseModel
-from pram_amd.nets.gml import GML as GMatcher
+from pram_amd.localization.matchers import _plugin
+from pram_amd.nets.gml import GML as _Net
 
 
 class GML(BaseModel):
-    # NB: like the reference this is `default_config`, which BaseModel (default_conf) never reads,
-    # so the network's own defaults apply.
-    default_config = {
-        'descriptor_dim': 128, 'hidden_dim': 256, 'weights': 'indoor', 'keypoint_encoder': [32, 64, 128, 256],
-        'GNN_layers': ['self', 'cross'] * 9, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_pose': False,
-        'n_layers': 9, 'n_min_tokens': 256, 'with_sinkhorn': True, 'ac_fn': 'relu', 'norm_fn': 'bn',
-        'weight_path': None,
-    }
-    required_inputs = ['image0', 'keypoints0', 'scores0', 'descriptors0',
-                       'image1', 'keypoints1', 'scores1', 'descriptors1']
-
     def _init(self, conf):
-        self.net = GMatcher(config=conf).eval()
-        state_dict = torch.load(conf['weight_path'], map_location='cpu')['model']
-        self.net.load_state_dict(state_dict, strict=True)
+        _plugin.init_from_checkpoint(self, _Net, conf)
 
     def _forward(self, data):
-        with torch.no_grad():
-            return self.net(data)
+        return _plugin.run(self, data)

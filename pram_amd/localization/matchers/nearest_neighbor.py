@@ -1,6 +1,8 @@
-"""Matcher plugin 'nearest_neighbor' (reference: localization/matchers/nearest_neighbor.py:5-56):
-mutual nearest neighbours on descriptor similarity, optional ratio / distance tests.
-sim = A·Bᵀ on the f32 MFMA GEMM, top-2 per row by wave reduction (ties -> lowest index)."""
+"""Matcher plugin 'nearest_neighbor': mutual nearest neighbours on descriptor similarity with optional ratio /
+distance tests (behaviour of the reference's localization/matchers/nearest_neighbor.py:5-56).
+
+sim = A·Bᵀ runs on the f32 MFMA GEMM; the per-row best / second-best (ties -> lowest index) come from one
+wave-reduction kernel instead of torch.topk."""
 import torch
 
 from pram_amd import ops
@@ -8,46 +10,44 @@ from pram_amd.localization.base_model import BaseModel
 from pram_amd.nets._blocks import require_cuda
 
 
-def find_nn(sim, ratio_thresh, distance_thresh, n_valid=None):
-    """sim [B,M,ld] -> matches int64 [B,M] (-1 none), scores [B,M]  (nearest_neighbor.py:5-17)"""
-    s0, s1, i0 = ops.row_top2(sim, largest=True, n_valid=n_valid)
-    d0, d1 = 2 * (1 - s0), 2 * (1 - s1)
-    mask = torch.ones_like(i0, dtype=torch.bool)
-    if ratio_thresh:
-        mask = mask & (d0 <= (ratio_thresh ** 2) * d1)
-    if distance_thresh:
-        mask = mask & (d0 <= distance_thresh ** 2)
-    matches = torch.where(mask, i0, i0.new_tensor(-1))
-    scores = torch.where(mask, (s0 + 1) / 2, s0.new_tensor(0))
-    return matches, scores
+def _nearest(a: torch.Tensor, b: torch.Tensor, ratio, max_dist):
+    """a [B,M,D], b [B,N,D] unit descriptors -> (match index int64 [B,M] or -1, score [B,M]).
+    Squared L2 distance of unit vectors is 2(1 - sim); accept when d0 <= ratio^2 * d1 and d0 <= max_dist^2."""
+    n = b.shape[1]
+    sim = ops.bgemm_nt(a, b, ldc=(n + 3) // 4 * 4)
+    best, second, idx = ops.row_top2(sim, largest=True, n_valid=n)
+    d_best, d_second = 2 * (1 - best), 2 * (1 - second)
+    accept = torch.ones_like(idx, dtype=torch.bool)
+    if ratio:
+        accept &= d_best <= (ratio ** 2) * d_second
+    if max_dist:
+        accept &= d_best <= max_dist ** 2
+    no_match = torch.full_like(idx, -1)
+    return torch.where(accept, idx, no_match), torch.where(accept, (best + 1) / 2, torch.zeros_like(best))
 
 
-def mutual_check(m0, m1):
-    """nearest_neighbor.py:20-25"""
-    inds0 = torch.arange(m0.shape[-1], device=m0.device)
-    loop = torch.gather(m1, -1, torch.where(m0 > -1, m0, m0.new_tensor(0)))
-    ok = (m0 > -1) & (inds0 == loop)
-    return torch.where(ok, m0, m0.new_tensor(-1))
+def _keep_mutual(m01: torch.Tensor, m10: torch.Tensor) -> torch.Tensor:
+    """Drop i -> j unless j -> i."""
+    rows = torch.arange(m01.shape[-1], device=m01.device)
+    back = torch.gather(m10, -1, m01.clamp(min=0))
+    return torch.where((m01 >= 0) & (back == rows), m01, torch.full_like(m01, -1))
 
 
 class NearestNeighbor(BaseModel):
     default_conf = {'ratio_threshold': None, 'distance_threshold': None, 'do_mutual_check': True}
-    required_inputs = ['descriptors0', 'descriptors1']
 
     def _init(self, conf):
         pass
 
     @torch.no_grad()
     def _forward(self, data):
-        d0, d1 = data['descriptors0'], data['descriptors1']      # [B, D, N], [B, D, M]  ('bdn,bdm->bnm')
+        d0, d1 = data['descriptors0'], data['descriptors1']        # [B, D, N] and [B, D, M], channel-major like the reference
         require_cuda(d0, "NearestNeighbor")
         a = d0.transpose(1, 2).contiguous().float()
         b = d1.transpose(1, 2).contiguous().float()
-        n, m = a.shape[1], b.shape[1]
-        sim = ops.bgemm_nt(a, b, ldc=(m + 3) // 4 * 4)
-        matches0, scores0 = find_nn(sim, self.conf['ratio_threshold'], self.conf['distance_threshold'], n_valid=m)
+        ratio, max_dist = self.conf['ratio_threshold'], self.conf['distance_threshold']
+        matches0, scores0 = _nearest(a, b, ratio, max_dist)
         if self.conf['do_mutual_check']:
-            sim_t = ops.bgemm_nt(b, a, ldc=(n + 3) // 4 * 4)
-            matches1, _ = find_nn(sim_t, self.conf['ratio_threshold'], self.conf['distance_threshold'], n_valid=n)
-            matches0 = mutual_check(matches0, matches1)
+            matches1, _ = _nearest(b, a, ratio, max_dist)
+            matches0 = _keep_mutual(matches0, matches1)
         return {'matches0': matches0, 'matching_scores0': scores0}
