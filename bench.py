@@ -208,13 +208,15 @@ def main():
         attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic = None
-    if (args.kpts, B, args.matcher, args.stages, args.n_class) == (2048, 8, "gml", "erm", 113):
+    if (args.kpts, B, args.matcher, args.stages, args.n_class, ops.attention_precision) == (2048, 8, "gml", "erm", 113, "f32"):
         try:   # HBM bytes per attention launch of THIS configuration, from the committed rocprofv3 --pmc passes
             traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
         except Exception:
             pass
-    roofline = {"bound": "mfma", "kernel": "attention_kernel (f32 MFMA flash attention)", "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+    f16 = ops.attention_precision == "f16"
+    peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS      # dense f16/bf16 MFMA peak vs f32 MFMA peak (MI355X_MICROARCH.md)
+    roofline = {"bound": "mfma", "kernel": "attention_f16_kernel (C5 fp16 MFMA path)" if f16 else "attention_kernel (f32 MFMA flash attention)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(attn_flops / max(1, len(probe)) / 512.0), "launches_per_step": len(probe), "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
                 "attention_share_of_step": round(attn_ms / (dt / args.steps * 1e3), 3)}
 
@@ -223,7 +225,9 @@ def main():
         line = {
             "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})", "value": round(total_q / dt, 3), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (attention operands f16: BASELINE C5 path, NOT the fp32 parity configuration)" if ops.attention_precision == "f16" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{'7Scenes' if args.n_class == 113 else 'custom'} full hot path: SFD2 extract+sample -> SegNetViT nc{args.n_class} (15 layers) -> "
                                    f"{args.matcher.upper()} match + 20 Sinkhorn iters vs a {args.kpts}-kpt reference set; "
                                    f"stages={args.stages}",

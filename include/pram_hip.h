@@ -82,6 +82,13 @@ int pram_attention_f32(const float* q, int ldq, const float* k, int ldk, const f
                        float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens,
                        int batch, int heads, int m_max, int n_max, float scale, void* stream);
 
+/* The "fp16 MFMA path" of BASELINE config C5: same contract as pram_attention_f32 (fp32 tensors in HBM),
+ * but Q/K/V and the probabilities are rounded to fp16 and multiplied on v_mfma_f32_32x32x16_f16 (fp32
+ * accumulate, fp32 softmax).  ~1e-3 relative error: NOT for the fp32 parity configs. */
+int pram_attention_f16_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                           float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens,
+                           int batch, int heads, int m_max, int n_max, float scale, void* stream);
+
 /* Column means of the attention matrix (AdaGML Attention.forward nets/adagml.py:148,229; K10):
  *   colmean[b][j] = 1/(heads*m_b) * sum_h sum_i softmax(scale q k^T)[b,h,i,j] */
 int pram_attention_colmean_f32(const float* q, int ldq, const float* k, int ldk, const float* lse2,

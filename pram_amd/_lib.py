@@ -24,6 +24,7 @@ _SIGS = {
     "pram_layernorm_gelu_f32": (I, [P, I, P, I, P, P, I, I, F, P]),
     "pram_fourier_encoding_f32": (I, [P, P, F, F, F, P, P, I, P]),
     "pram_attention_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P]),
+    "pram_attention_f16_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P]),
     "pram_attention_colmean_f32": (I, [P, I, P, I, P, P, P, P, I, I, I, I, F, P]),
     "pram_sinkhorn_workspace_bytes": (SZ, [I, I, I]),
     "pram_sinkhorn_match_f32": (I, [P, I, P, P, P, I, F, P, I, P, P, P, P, I, I, I, P, P]),

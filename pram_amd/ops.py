@@ -105,10 +105,15 @@ def fourier_encoding(kpts: torch.Tensor, wr: torch.Tensor, cx: float, cy: float,
 # launch stream and (algorithmic flops, start, stop) is appended.  None (default) = no events.
 attention_probe = None
 
+# "f32" (default; exact-fp32 MFMA, the parity path) or "f16" (BASELINE config C5's fp16 MFMA path: fp16 operands,
+# fp32 accumulate / softmax, ~1e-3 relative error).  Set per process via PRAM_ATTENTION_PRECISION or at run time.
+import os as _os
+attention_precision = _os.environ.get("PRAM_ATTENTION_PRECISION", "f32")
+
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int,
               scale: float, q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None,
-              want_lse: bool = False, out: Optional[torch.Tensor] = None):
+              want_lse: bool = False, out: Optional[torch.Tensor] = None, precision: Optional[str] = None):
     """q/k/v: 2-D row-major views (possibly column slices of a wider buffer): q [batch*m_max, >=heads*64]."""
     L = _lib.load()
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):
@@ -121,9 +126,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.pram_attention_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
-                                    _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
-               "pram_attention_f32")
+    prec = precision or attention_precision
+    if prec not in ("f32", "f16"):
+        raise _lib.PramHipError(f"unknown attention precision {prec!r}")
+    fn = L.pram_attention_f32 if prec == "f32" else L.pram_attention_f16_f32
+    _lib.check(fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                  _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
+               "pram_attention_" + prec)
     if probe is not None:
         e1.record()
         # algorithmic FLOPs of QK^T + PV: 4 * m_b * n_b * 64 per (batch element, head), from the ACTUAL ragged

@@ -110,6 +110,32 @@ def test_attention_vs_fp64(dev, B, M, N):
     assert H.maxdiff(col, a.mean(1).mean(1)) < 1e-6
 
 
+@pytest.mark.parametrize("B,M,N", [(1, 128, 64), (2, 300, 333), (1, 70, 1000), (1, 2048, 2048)])
+def test_attention_f16_path(dev, B, M, N):
+    """C5 'fp16 MFMA path': fp16 operands, fp32 accumulate.  Documented tolerance: 4e-3 abs on O(1) outputs vs fp64
+    (operand rounding 2^-11), and much tighter vs an fp64 reference fed the SAME fp16-rounded q, k, v (layout check)."""
+    from pram_amd import ops
+    Hh = 4
+    q, k, v = rnd(4, "at/q", (B, Hh, M, 64)), rnd(4, "at/k", (B, Hh, N, 64)), rnd(4, "at/v", (B, Hh, N, 64))
+    ref, _ = _attn_ref(q, k, v, 0.125)
+    ref16, _ = _attn_ref(q.half().float(), k.half().float(), v.half().float(), 0.125)
+    to2d = lambda t, L: t.permute(0, 2, 1, 3).reshape(B * L, Hh * 64).contiguous().to(dev)
+    out, lse = ops.attention(to2d(q, M), to2d(k, N), to2d(v, N), B, Hh, M, N, 0.125, want_lse=True, precision="f16")
+    out = out.cpu().view(B, M, Hh, 64).permute(0, 2, 1, 3)
+    d, d16 = H.maxdiff(out, ref), H.maxdiff(out, ref16)
+    print(f"f16 attention {B}x{M}x{N}: |o - fp64| {d:.2e}, |o - fp64(fp16 inputs)| {d16:.2e}")
+    assert d < 4e-3 and d16 < 1.5e-3
+    # ragged: padded element == unpadded run, bit for bit
+    if B == 2:
+        L = torch.tensor([M, M - 77], dtype=torch.int32, device=dev)
+        Lk = torch.tensor([N, N - 100], dtype=torch.int32, device=dev)
+        o2 = ops.attention(to2d(q, M), to2d(k, N), to2d(v, N), B, Hh, M, N, 0.125, L, Lk, precision="f16").view(B, M, 256)
+        one = lambda t: t[1].permute(1, 0, 2).reshape(t.shape[2], Hh * 64).contiguous().to(dev)
+        solo = ops.attention(one(q[:, :, :M - 77]), one(k[:, :, :N - 100]), one(v[:, :, :N - 100]),
+                             1, Hh, M - 77, N - 100, 0.125, precision="f16")
+        assert torch.equal(o2[1, :M - 77], solo)
+
+
 def test_attention_spiked_key_forces_rescale(dev):
     """One key dominates one query late in the sequence: the running max jumps mid-stream (online-softmax rescale)."""
     from pram_amd import ops

@@ -83,6 +83,31 @@ def test_segnetvit_ragged_batch(dev):
         assert torch.equal(out[b, :n], solo[0])
 
 
+def test_c5_fp16_attention_path_tolerance(dev):
+    """BASELINE config C5 ('fp16 MFMA path', 4096 keypoints): fp16-operand attention inside the otherwise-fp32 models.
+    Own, looser, documented tolerance: logits within 3e-2 of the fp32 oracle, argmax agreement >= 99 %; matcher index
+    agreement >= 98 % (indices are NOT promised bit-exact on this path)."""
+    from pram_amd import ops
+    desc, kp = _tokens(1, 4096)
+    ref = R.segnetvit_forward(H.segnet_sd(161), desc, kp, (1, 3, 480, 640))
+    data, _ = H.pair_data(0, 1024, 1024)
+    refm = R.gml_produce_matches(H.gml_sd(), data, p=0.2)
+    old = ops.attention_precision
+    ops.attention_precision = "f16"
+    try:
+        out = _segnet(dev, 161)({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"]
+        rm = _gml(dev)({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()})
+    finally:
+        ops.attention_precision = old
+    d = H.maxdiff(out, ref)
+    agree = (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean().item()
+    magree = (rm["matches0"].cpu() == refm["matches0"]).float().mean().item()
+    ds = H.maxdiff(rm["matching_scores0"], refm["matching_scores0"])
+    print(f"C5 fp16 attention: segnetvit N=4096 nc161 |logit - oracle| {d:.2e}, argmax agreement {agree:.4f}; "
+          f"gml 1024x1024 index agreement {magree:.4f}, score diff {ds:.2e}")
+    assert d < 3e-2 and agree >= 0.99 and magree >= 0.98
+
+
 def _gml(dev):
     from pram_amd.nets.gml import GML
     g = GML({})
