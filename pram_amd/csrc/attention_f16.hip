@@ -51,7 +51,7 @@ __device__ __forceinline__ int pos_of_key(int key) {
     return t * 32 + u * 16 + h * 8 + i;
 }
 
-__global__ __launch_bounds__(256, 2) void attention_f16_kernel(Args p) {
+__global__ __launch_bounds__(256, 3) void attention_f16_kernel(Args p) {
     __shared__ Smem s;
     const int nblk = p.batch * p.heads * p.q_tiles;
     const int id = xcd_remap(blockIdx.x, nblk);
@@ -162,14 +162,14 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(Args p) {
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax * p.scale2);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float psum = 0.f;
             half8 pf[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = exp2f(fmaf(st[t][e], p.scale2, -m_new));
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, -m_new));   // v_exp_f32: argument <= 0
                     psum += pv;
                     pf[t][e >> 3][e & 7] = (_Float16)pv;
                 }
