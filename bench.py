@@ -208,7 +208,7 @@ def main():
         attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic = None
-    if (args.kpts, B, args.matcher, args.stages, args.n_class, ops.attention_precision) == (2048, 8, "gml", "erm", 113, "f32"):
+    if (args.kpts, B, args.matcher, args.stages, args.n_class, ops.attention_precision) == (2048, 8, "gml", "erm", 113, "f32") and ops.gemm_precision == "f32":
         try:   # HBM bytes per attention launch of THIS configuration, from the committed rocprofv3 --pmc passes
             traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
         except Exception:
@@ -226,7 +226,9 @@ def main():
             "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})", "value": round(total_q / dt, 3), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (attention operands f16: BASELINE C5 path, NOT the fp32 parity configuration)" if ops.attention_precision == "f16" else "f32",
+            "dtype": "f32" if (ops.attention_precision, ops.gemm_precision) == ("f32", "f32") else
+                     f"f16 operands / f32 accumulate (attention {ops.attention_precision}, GEMM+conv {ops.gemm_precision}): "
+                     "BASELINE C5 'fp16 MFMA path', NOT the fp32 parity configuration",
             "data": "synthetic",
             "config": {"workload": f"{'7Scenes' if args.n_class == 113 else 'custom'} full hot path: SFD2 extract+sample -> SegNetViT nc{args.n_class} (15 layers) -> "
                                    f"{args.matcher.upper()} match + 20 Sinkhorn iters vs a {args.kpts}-kpt reference set; "

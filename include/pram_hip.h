@@ -53,6 +53,15 @@ int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1
                     float* out, int ldo, int m, int n, float alpha, int flags,
                     const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
 
+/* fp16-operand variant for BASELINE config C5 ("fp16 MFMA path"): identical contract, but `w16` is the weight
+ * matrix pre-converted to IEEE fp16 ([n][k0+k1]) and the activations are rounded to fp16 on their way into LDS;
+ * products on v_mfma_f32_32x32x16_f16, fp32 accumulate and epilogue.  Needs (k0+k1) % 8 == 0 and, with a
+ * second segment, k0 % 64 == 0.  Not for the fp32 parity configurations. */
+int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                        const void* w16, const float* bias, const float* residual, int ldr,
+                        float* out, int ldo, int m, int n, float alpha, int flags,
+                        const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
+
 /* Batched C_b = alpha * A_b · B_bᵀ (einsum 'bmd,bnd->bmn', nets/gml.py:282; K12).
  * A_b = a + b*stride_a, [m_max][lda]; B_b [n_max][ldb]; C_b [m_max][ldc]. */
 int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
@@ -150,6 +159,12 @@ int pram_conv2d_nhwc_f32(const float* in, int batch, int h, int w, int cin, cons
                          const float* bias, const float* scale, const float* shift,
                          const float* residual, float* out, int cout, int ks, int stride, int relu,
                          void* stream);
+
+/* fp16-operand variant (BASELINE C5): wgt16 = [cout][ks][ks][cin] in fp16, cin % 64 == 0. */
+int pram_conv2d_nhwc_f16_f32(const float* in, int batch, int h, int w, int cin, const void* wgt16,
+                             const float* bias, const float* scale, const float* shift,
+                             const float* residual, float* out, int cout, int ks, int stride, int relu,
+                             void* stream);
 
 /* Grouped 3x3 convolution of the ResBlock (groups = 32, 8 ch/group; nets/sfd2.py:98-99,113-115).
  * w [c][3][3][c/groups]. */

@@ -20,6 +20,7 @@ _SIGS = {
     "pram_hip_version": (I, []),
     "pram_last_error": (C.c_char_p, []),
     "pram_linear_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
+    "pram_linear_f16_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_bgemm_nt_f32": (I, [P, I, LL, P, I, LL, P, I, LL, I, I, I, I, F, P]),
     "pram_layernorm_gelu_f32": (I, [P, I, P, I, P, P, I, I, F, P]),
     "pram_fourier_encoding_f32": (I, [P, P, F, F, F, P, P, I, P]),
@@ -32,6 +33,7 @@ _SIGS = {
     "pram_adagml_prune_f32": (I, [P, F, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "pram_adagml_scatter_f32": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "pram_conv2d_nhwc_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),
+    "pram_conv2d_nhwc_f16_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),
     "pram_conv3x3_grouped_nhwc_f32": (I, [P, I, I, I, I, P, P, P, P, I, I, P]),
     "pram_image_to_nhwc4_f32": (I, [P, P, I, I, I, P]),
     "pram_nhwc_to_nchw_f32": (I, [P, P, I, I, I, I, P]),

@@ -8,6 +8,7 @@
 // zero padding); everything after that is gemm_core.h.  Eval-mode BatchNorm is applied as a
 // per-channel scale/shift in the epilogue (same op order as conv -> BN), then residual, then ReLU.
 #include "gemm_core.h"
+#include "gemm_core_f16.h"
 
 namespace {
 
@@ -18,6 +19,56 @@ struct ConvArgs {
     int ho, wo, m, k;
     int tiles_m, tiles_n;
 };
+
+// Shared epilogue of the fp32 and fp16 main loops: bias -> BN scale/shift -> residual -> ReLU.
+template <int MI, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MI][2], int row0, int col0, int BM, int BN) {
+    using gemm::acc_row;
+    const int tid = threadIdx.x;
+    const int nlast = p.cout - 1;
+    // loads first, predicated stores last
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int mlast = p.m - 1;
+    const int rbase = row0 + wm * 32 * MI;
+    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.cout);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = col0 + wn * 64 + ni * 32 + r;
+        const int cc = min(col, nlast);
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float sh = p.scale ? p.shift[cc] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float q[16];
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    q[e] = p.residual[(size_t)min(rbase + acc_row(mi, e, h), mlast) * p.cout + cc];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[mi][ni][e] + bi;
+                if (p.scale) v = v * sc + sh;
+                if (p.residual) v += q[e];
+                if (p.relu) v = fmaxf(v, 0.f);
+                q[e] = v;
+            }
+            if (full) {   // block-uniform fast path
+#pragma unroll
+                for (int e = 0; e < 16; ++e) p.out[(size_t)(rbase + acc_row(mi, e, h)) * p.cout + col] = q[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rbase + acc_row(mi, e, h);
+                    if (row < p.m && col < p.cout) p.out[(size_t)row * p.cout + col] = q[e];
+                }
+            }
+        }
+    }
+}
 
 template <bool CIN4, int MI, int WN>
 __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
@@ -89,48 +140,63 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
     f32x16 acc[MI][2];
     mainloop<MI, WN>(smem, la, oka, lb, okb, (p.k + BK - 1) / BK, acc);
 
-    // ---- epilogue: bias -> BN scale/shift -> residual -> ReLU; loads first, predicated stores last
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, h = lane >> 5;
-    const int mlast = p.m - 1;
-    const int rbase = row0 + wm * 32 * MI;
-    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.cout);
+    conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
+}
+
+// fp16-operand variant (BASELINE C5): w16 = [cout][ks][ks][cin] in fp16, cin % 64 == 0 (a 64-deep chunk never
+// straddles taps).
+template <int MI, int WN>
+__global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, const _Float16* __restrict__ w16) {
+    using namespace gemm16;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int tid = threadIdx.x;
+    const int arow = tid >> 4, akq = tid & 15, brow = tid >> 3, bsl = tid & 7;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int pad = p.ks >> 1;
+    int iy0[C::PA], ix0[C::PA];
+    const float* base[C::PA];
+    bool ok[C::PA];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = col0 + wn * 64 + ni * 32 + r;
-        const int cc = min(col, nlast);
-        const float bi = p.bias ? p.bias[cc] : 0.f;
-        const float sc = p.scale ? p.scale[cc] : 1.f;
-        const float sh = p.scale ? p.shift[cc] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            float q[16];
-            if (p.residual) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    q[e] = p.residual[(size_t)min(rbase + acc_row(mi, e, h), mlast) * p.cout + cc];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[mi][ni][e] + bi;
-                if (p.scale) v = v * sc + sh;
-                if (p.residual) v += q[e];
-                if (p.relu) v = fmaxf(v, 0.f);
-                q[e] = v;
-            }
-            if (full) {   // block-uniform fast path
-#pragma unroll
-                for (int e = 0; e < 16; ++e) p.out[(size_t)(rbase + acc_row(mi, e, h)) * p.cout + col] = q[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = rbase + acc_row(mi, e, h);
-                    if (row < p.m && col < p.cout) p.out[(size_t)row * p.cout + col] = q[e];
-                }
-            }
-        }
+    for (int pp = 0; pp < C::PA; ++pp) {
+        const int row = row0 + arow + 16 * pp;
+        ok[pp] = row < p.m;
+        const int rr = ok[pp] ? row : 0;
+        const int ox = rr % p.wo;
+        const int t = rr / p.wo;
+        const int oy = t % p.ho;
+        const int b = t / p.ho;
+        iy0[pp] = oy * p.stride - pad;
+        ix0[pp] = ox * p.stride - pad;
+        base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
     }
+    const int nlast = p.cout - 1;
+    auto la = [&](int pp, int kt) -> float4 {
+        const int k = kt * BK;
+        const int tap = k / p.cin;
+        const int ci = k - tap * p.cin + akq * 4;
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        const int iyc = min(max(iy0[pp] + ky, 0), p.h - 1), ixc = min(max(ix0[pp] + kx, 0), p.wd - 1);
+        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + ci);
+    };
+    auto oka = [&](int pp, int kt) -> bool {
+        const int tap = (kt * BK) / p.cin;
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
+        return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+    };
+    auto lb = [&](int pp, int kt) -> uint4 {
+        const int cc = min(col0 + brow + 32 * pp, nlast);
+        return *reinterpret_cast<const uint4*>(w16 + (size_t)cc * p.k + kt * BK + bsl * 8);
+    };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 32 * pp) < p.cout; };
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, la, oka, lb, okb, p.k / BK, acc);
+    conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 
 // ---------------------------------------------------------------- grouped 3x3 (VALU)
@@ -277,6 +343,37 @@ extern "C" int pram_conv2d_nhwc_f32(const float* in, int batch, int h, int w, in
     else { if (mi == 2) LAUNCH(false, 2, 2); else LAUNCH(false, 1, 2); }
 #undef LAUNCH
     return pram_launch_status("pram_conv2d_nhwc_f32");
+}
+
+extern "C" int pram_conv2d_nhwc_f16_f32(const float* in, int batch, int h, int w, int cin, const void* wgt16,
+                                        const float* bias, const float* scale, const float* shift, const float* residual,
+                                        float* out, int cout, int ks, int stride, int relu, void* stream) {
+    PRAM_REQUIRE(in && wgt16 && out, "pram_conv2d_nhwc_f16_f32: null pointer");
+    PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_f16_f32: ks must be 1 or 3");
+    PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_f16_f32: stride must be 1 or 2");
+    PRAM_REQUIRE(cin % 64 == 0, "pram_conv2d_nhwc_f16_f32: cin=%d must be a multiple of 64", cin);
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_f16_f32: scale and shift go together");
+    if (batch == 0) return PRAM_OK;
+    const int pad = ks / 2;
+    ConvArgs p{in, nullptr, bias, scale, shift, residual, out, batch, h, w, cin, cout, ks, stride, relu};
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    p.m = batch * p.ho * p.wo;
+    p.k = ks * ks * cin;
+    int mi, wn;
+    gemm::choose_tile(p.m, cout, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* w16 = (const _Float16*)wgt16;
+#define LAUNCH16(MI_, WN_)                                                                                          \
+    do {                                                                                                            \
+        p.tiles_m = cdiv(p.m, gemm16::Cfg<MI_, WN_>::BM);                                                           \
+        p.tiles_n = cdiv(cout, gemm16::Cfg<MI_, WN_>::BN);                                                          \
+        hipLaunchKernelGGL((conv_f16_kernel<MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemm16::NT), 0, st, p, w16); \
+    } while (0)
+    if (wn == 1) { if (mi == 2) LAUNCH16(2, 1); else LAUNCH16(1, 1); }
+    else { if (mi == 2) LAUNCH16(2, 2); else LAUNCH16(1, 2); }
+#undef LAUNCH16
+    return pram_launch_status("pram_conv2d_nhwc_f16_f32");
 }
 
 extern "C" int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int c, const float* wgt,

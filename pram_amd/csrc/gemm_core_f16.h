@@ -1,0 +1,114 @@
+// fp16-operand / fp32-accumulate GEMM main loop (v_mfma_f32_32x32x16_f16) for the "fp16 MFMA path" of
+// BASELINE config C5.  Same tiling idea and the same accumulator layout as gemm_core.h (so the epilogues are
+// shared), but K is consumed in chunks of 64 and the operands are rounded to fp16 on their way into LDS:
+//   * A (activations / im2col) is fp32 in HBM: 16 threads read one 256-B row segment as float4, convert to
+//     4 x fp16 and store 8 bytes;
+//   * B (weights) is pre-converted to fp16 once on the host: 8 threads read one 128-B row segment as 16-B loads.
+// LDS rows are 128 B (64 fp16); the 16-B slot is XOR-swizzled with (row >> 1) & 7 (conflict-free ds_read_b128:
+// a 16-lane group touches 16 distinct (bank-row half, slot) pairs).  At the fp16 rate (32 cycles per MFMA)
+// a chunk is only 16 MFMA = 512 matrix cycles per wave, so these GEMMs are staging/HBM-bound, not matrix-bound.
+#pragma once
+#include "common.h"
+
+namespace gemm16 {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64, NT = 256;
+
+template <int MI, int WN>
+struct Cfg {
+    static constexpr int WM = 4 / WN;
+    static constexpr int BM = WM * 32 * MI;
+    static constexpr int BN = WN * 64;
+    static constexpr int PA = BM / 16;   // float4 (fp32) staging loads per thread for A
+    static constexpr int PB = BN / 32;   // 16-byte (8 x fp16) staging loads per thread for B
+};
+
+template <int MI, int WN>
+struct alignas(16) Smem {
+    _Float16 a[2][Cfg<MI, WN>::BM * BK];
+    _Float16 b[2][Cfg<MI, WN>::BN * BK];
+};  // <2,2>: 64 KiB
+
+__device__ __forceinline__ int swz(int slot, int row) { return slot ^ ((row >> 1) & 7); }
+
+// ALoad(p, kt) -> raw float4 A[row = tid/16 + 16p][kt*64 + (tid%16)*4 ..+3];  AOk(p, kt) its predicate
+// BLoad(p, kt) -> raw uint4  W[col = tid/8 + 32p][kt*64 + (tid%8)*8 ..+7] (fp16); BOk(p, kt) its predicate
+template <int MI, int WN, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         f32x16 (&acc)[MI][2]) {
+    using C = Cfg<MI, WN>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int arow = tid >> 4, akq = tid & 15;
+    const int brow = tid >> 3, bsl = tid & 7;
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    float4 ra[C::PA];
+    uint4 rb[C::PB];
+    auto stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int p = 0; p < C::PA; ++p) {
+            const int row = arow + 16 * p;
+            float4 v = ra[p];
+            if (!oka(p, kt)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            half4 hv;
+            hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+            *reinterpret_cast<half4*>(&s.a[buf][row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4]) = hv;
+        }
+#pragma unroll
+        for (int p = 0; p < C::PB; ++p) {
+            const int row = brow + 32 * p;
+            uint4 v = rb[p];
+            if (!okb(p, kt)) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(&s.b[buf][row * BK + swz(bsl, row) * 8]) = v;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < C::PA; ++p) ra[p] = la(p, 0);
+#pragma unroll
+    for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, 0);
+    stage(0, 0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < C::PA; ++p) ra[p] = la(p, kt + 1);
+#pragma unroll
+            for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, kt + 1);
+        }
+        const _Float16* sa = &s.a[cur][(wm * 32 * MI + r) * BK];
+        const _Float16* sb = &s.b[cur][(wn * 64 + r) * BK];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int slot = swz(2 * st + h, r) * 8;      // rows differ from r by multiples of 32: same swizzle
+            half8 af[MI], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const half8*>(sa + mi * 32 * BK + slot);
+            bf[0] = *reinterpret_cast<const half8*>(sb + slot);
+            bf[1] = *reinterpret_cast<const half8*>(sb + 32 * BK + slot);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[0], acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[1], acc[mi][1], 0, 0, 0);
+            }
+        }
+        if (more) stage(cur ^ 1, kt + 1);
+        __syncthreads();
+    }
+}
+
+}  // namespace gemm16

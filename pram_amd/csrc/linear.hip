@@ -2,6 +2,7 @@
 // epilogue), batched A·Bᵀ, LayerNorm+GELU, Fourier positional encoding.
 // Reference sites: nets/segnetvit.py:87-106,157-164; nets/gml.py:118-186,220,235,278-282.
 #include "gemm_core.h"
+#include "gemm_core_f16.h"
 
 namespace {
 
@@ -21,46 +22,14 @@ struct LinArgs {
     int tiles_m, tiles_n;
 };
 
+// Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
 template <int MI, int WN>
-__global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
-    using namespace gemm;
-    using C = Cfg<MI, WN>;
-    constexpr int BM = C::BM, BN = C::BN;
-    __shared__ Smem<MI, WN> smem;
-    const int nblk = p.tiles_m * p.tiles_n;
-    const int id = xcd_remap(blockIdx.x, nblk);
-    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
-    const int z = blockIdx.y;
-    const float* a0 = p.a0 + z * p.sa;
-    const float* w = p.w + z * p.sw;
-    float* out = p.out + z * p.so;
-    const int K = p.k0 + p.k1;
+__device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[MI][2], float* out, int row0, int col0,
+                                                int BM, int BN) {
+    using gemm::acc_row;
     const int tid = threadIdx.x;
-    const int srow = tid >> 3, skq = tid & 7;
-    const int row0 = tm * BM, col0 = tn * BN;
-
-    // loaders: clamped (always legal) addresses + select, no branches around the loads
-    const int mlast = p.m - 1, nlast = p.n - 1, klast = K - 4;
-    auto la = [&](int pp, int kt) -> float4 {
-        const int row = row0 + srow + 32 * pp;
-        const int k = kt * BK + skq * 4;
-        const int rc = min(row, mlast), kc = min(k, klast);
-        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
-        const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (a0 + (size_t)rc * p.lda0 + kc);
-        return *reinterpret_cast<const float4*>(src);
-    };
-    auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + 32 * pp) < p.m && (kt * BK + skq * 4) < K; };
-    auto lb = [&](int pp, int kt) -> float4 {
-        const int col = col0 + srow + 32 * pp;
-        const int k = kt * BK + skq * 4;
-        return *reinterpret_cast<const float4*>(w + (size_t)min(col, nlast) * K + min(k, klast));
-    };
-    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.n && (kt * BK + skq * 4) < K; };
-
-    f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, la, oka, lb, okb, (K + BK - 1) / BK, acc);
-
-    // ---- epilogue: all loads first (clamped addresses), then arithmetic, then predicated stores
+    const int mlast = p.m - 1, nlast = p.n - 1;
+    // all loads first (clamped addresses), then arithmetic, then predicated stores
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
@@ -123,6 +92,82 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
             }
         }
     }
+}
+
+template <int MI, int WN>
+__global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
+    using namespace gemm;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int z = blockIdx.y;
+    const float* a0 = p.a0 + z * p.sa;
+    const float* w = p.w + z * p.sw;
+    float* out = p.out + z * p.so;
+    const int K = p.k0 + p.k1;
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, skq = tid & 7;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // loaders: clamped (always legal) addresses + select, no branches around the loads
+    const int mlast = p.m - 1, nlast = p.n - 1, klast = K - 4;
+    auto la = [&](int pp, int kt) -> float4 {
+        const int row = row0 + srow + 32 * pp;
+        const int k = kt * BK + skq * 4;
+        const int rc = min(row, mlast), kc = min(k, klast);
+        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
+        const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (a0 + (size_t)rc * p.lda0 + kc);
+        return *reinterpret_cast<const float4*>(src);
+    };
+    auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + 32 * pp) < p.m && (kt * BK + skq * 4) < K; };
+    auto lb = [&](int pp, int kt) -> float4 {
+        const int col = col0 + srow + 32 * pp;
+        const int k = kt * BK + skq * 4;
+        return *reinterpret_cast<const float4*>(w + (size_t)min(col, nlast) * K + min(k, klast));
+    };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.n && (kt * BK + skq * 4) < K; };
+
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+
+    linear_epilogue<MI, WN>(p, acc, out, row0, col0, BM, BN);
+}
+
+// fp16-operand variant (BASELINE C5 "fp16 MFMA path"): w16 is the weight matrix pre-converted to fp16.
+template <int MI, int WN>
+__global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, const _Float16* __restrict__ w16) {
+    using namespace gemm16;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int K = p.k0 + p.k1;
+    const int tid = threadIdx.x;
+    const int arow = tid >> 4, akq = tid & 15, brow = tid >> 3, bsl = tid & 7;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int mlast = p.m - 1, nlast = p.n - 1;
+    auto la = [&](int pp, int kt) -> float4 {
+        const int rc = min(row0 + arow + 16 * pp, mlast);
+        const int kc = min(kt * BK + akq * 4, K - 4);
+        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 64 == 0
+        const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (p.a0 + (size_t)rc * p.lda0 + kc);
+        return *reinterpret_cast<const float4*>(src);
+    };
+    auto oka = [&](int pp, int kt) -> bool { return (row0 + arow + 16 * pp) < p.m && (kt * BK + akq * 4) < K; };
+    auto lb = [&](int pp, int kt) -> uint4 {
+        const int cc = min(col0 + brow + 32 * pp, nlast);
+        const int kc = min(kt * BK + bsl * 8, K - 8);
+        return *reinterpret_cast<const uint4*>(w16 + (size_t)cc * K + kc);
+    };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 32 * pp) < p.n && (kt * BK + bsl * 8) < K; };
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
 }
 
 // ---------------------------------------------------------------- LayerNorm + GELU
@@ -197,7 +242,37 @@ void launch_linear(LinArgs& p, int batch, hipStream_t st) {
     else         { if (mi == 2) launch_linear_t<2, 1>(p, batch, st); else launch_linear_t<1, 1>(p, batch, st); }
 }
 
+template <int MI, int WN>
+void launch_linear_f16_t(LinArgs& p, const _Float16* w16, hipStream_t st) {
+    using C = gemm16::Cfg<MI, WN>;
+    p.tiles_m = cdiv(p.m, C::BM);
+    p.tiles_n = cdiv(p.n, C::BN);
+    hipLaunchKernelGGL((linear_f16_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemm16::NT), 0, st, p, w16);
+}
+
 }  // namespace
+
+extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
+                                   const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                                   float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                                   void* stream) {
+    PRAM_REQUIRE(a0 && w16 && out, "pram_linear_f16_f32: null pointer");
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "pram_linear_f16_f32: bad sizes");
+    PRAM_REQUIRE((k0 + k1) % 8 == 0 && lda0 % 4 == 0, "pram_linear_f16_f32: K must be a multiple of 8, lda of 4");
+    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemm16::BK == 0 && lda1 % 4 == 0), "pram_linear_f16_f32: concat needs k0 %% 64 == 0");
+    if (flags & PRAM_LIN_ROTARY)
+        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_f16_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
+    if (m == 0) return PRAM_OK;
+    LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0};
+    int mi, wn;
+    gemm::choose_tile(m, n, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* w = (const _Float16*)w16;
+    if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
+    else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
+    return pram_launch_status("pram_linear_f16_f32");
+}
 
 extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
                                const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,

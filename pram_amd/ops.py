@@ -59,6 +59,12 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if rotary is not None:
         rc, rs, rcols = rotary
         flags = 1
+    use16 = gemm_precision == "f16" and (k0 + k1) % 64 == 0 and (k1 == 0 or k0 % 64 == 0)
+    if use16:
+        _lib.check(L.pram_linear_f16_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual),
+                                         n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+                   "pram_linear_f16_f32")
+        return out
     _lib.check(L.pram_linear_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(w), _p(bias), _p(residual),
                                  n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
                "pram_linear_f32")
@@ -109,6 +115,19 @@ attention_probe = None
 # fp32 accumulate / softmax, ~1e-3 relative error).  Set per process via PRAM_ATTENTION_PRECISION or at run time.
 import os as _os
 attention_precision = _os.environ.get("PRAM_ATTENTION_PRECISION", "f32")
+# same switch for the token GEMMs and the SFD2 convolutions (fp16 operands, fp32 accumulate / epilogue)
+gemm_precision = _os.environ.get("PRAM_GEMM_PRECISION", "f32")
+_w16_cache = {}
+
+
+def _w16(w: torch.Tensor) -> torch.Tensor:
+    """fp16 copy of a (static) weight tensor, converted once per device buffer."""
+    key = (w.data_ptr(), tuple(w.shape))
+    h = _w16_cache.get(key)
+    if h is None:
+        h = w.half().contiguous()
+        _w16_cache[key] = h
+    return h
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int,
@@ -229,6 +248,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=N
     pad = ks // 2
     Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
     out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    if gemm_precision == "f16" and Cin % 64 == 0:
+        _lib.check(L.pram_conv2d_nhwc_f16_f32(_p(x), B, H, W, Cin, _p(_w16(w)), _p(bias), _p(scale), _p(shift), _p(residual),
+                                              _p(out), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f16_f32")
+        return out
     _lib.check(L.pram_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(w), _p(bias), _p(scale), _p(shift), _p(residual), _p(out),
                                       Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f32")
     return out

@@ -42,6 +42,46 @@ def test_linear(dev, m, k0, k1, n):
         assert H.maxdiff(ops.linear(x.to(dev), w.to(dev)), F.linear(x, w)) < 2e-5
 
 
+@pytest.mark.parametrize("m,k0,k1,n", [(300, 256, 0, 768), (1000, 256, 256, 512), (77, 1024, 0, 113), (513, 512, 0, 256)])
+def test_linear_f16_path(dev, m, k0, k1, n):
+    """C5 fp16 MFMA GEMM: exact (to fp32 accumulation order) against a reference fed the SAME fp16-rounded operands,
+    and within the documented 2e-2 of the fp32 result."""
+    from pram_amd import ops
+    x = rnd(1, "lin/x", (m, k0))
+    x2 = rnd(1, "lin/x2", (m, k1)) if k1 else None
+    w = rnd(1, "lin/w", (n, k0 + k1), 1.0 / math.sqrt(k0 + k1))
+    b = rnd(1, "lin/b", (n,), 0.1)
+    res = rnd(1, "lin/r", (m, n))
+    xa = torch.cat([x, x2], -1) if k1 else x
+    ref = F.linear(xa, w, b) * 0.25 + res
+    ref16 = F.linear(xa.half().double(), w.half().double(), b.double()).float() * 0.25 + res
+    old = ops.gemm_precision
+    ops.gemm_precision = "f16"
+    try:
+        out = ops.linear(x.to(dev), w.to(dev), b.to(dev), x2=None if x2 is None else x2.to(dev), residual=res.to(dev), alpha=0.25)
+    finally:
+        ops.gemm_precision = old
+    print(f"f16 linear {m}x{k0}+{k1}x{n}: vs fp16-operand fp64 {H.maxdiff(out, ref16):.2e}, vs fp32 {H.maxdiff(out, ref):.2e}")
+    assert H.maxdiff(out, ref16) < 2e-5 and H.maxdiff(out, ref) < 2e-2
+
+
+def test_conv_f16_path(dev):
+    from pram_amd import ops
+    from pram_amd.nets.sfd2 import ResNet4x
+    for cin, cout, ks, stride, h, w in ((64, 64, 3, 2, 40, 56), (128, 256, 3, 1, 30, 40), (256, 65, 1, 1, 15, 20), (256, 256, 3, 1, 24, 32)):
+        x = rnd(7, "cv/x", (2, cin, h, w))
+        wt = rnd(7, "cv/w", (cout, cin, ks, ks), 1.0 / math.sqrt(cin * ks * ks))
+        b = rnd(7, "cv/b", (cout,), 0.1)
+        ref16 = F.conv2d(x.half().double(), wt.half().double(), b.double(), stride=stride, padding=ks // 2).float()
+        old = ops.gemm_precision
+        ops.gemm_precision = "f16"
+        try:
+            out = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), ResNet4x._ohwi(wt).to(dev), b.to(dev), ks=ks, stride=stride)
+        finally:
+            ops.gemm_precision = old
+        assert H.maxdiff(out.permute(0, 3, 1, 2), ref16) < 2e-5
+
+
 def test_linear_mfma_layout_asymmetric(dev):
     """A = I-like check with asymmetric B: catches row/col swaps in the MFMA fragment maps."""
     from pram_amd import ops

@@ -92,7 +92,7 @@ def test_c5_fp16_attention_path_tolerance(dev):
     ref = R.segnetvit_forward(H.segnet_sd(161), desc, kp, (1, 3, 480, 640))
     data, _ = H.pair_data(0, 1024, 1024)
     refm = R.gml_produce_matches(H.gml_sd(), data, p=0.2)
-    old = ops.attention_precision
+    old, oldg = ops.attention_precision, ops.gemm_precision
     ops.attention_precision = "f16"
     try:
         out = _segnet(dev, 161)({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"]
@@ -106,6 +106,18 @@ def test_c5_fp16_attention_path_tolerance(dev):
     print(f"C5 fp16 attention: segnetvit N=4096 nc161 |logit - oracle| {d:.2e}, argmax agreement {agree:.4f}; "
           f"gml 1024x1024 index agreement {magree:.4f}, score diff {ds:.2e}")
     assert d < 3e-2 and agree >= 0.99 and magree >= 0.98
+    # full fp16 MFMA path: attention AND token GEMMs with fp16 operands (fp32 accumulate / softmax / LayerNorm)
+    ops.attention_precision = ops.gemm_precision = "f16"
+    try:
+        out = _segnet(dev, 161)({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"]
+        rm = _gml(dev)({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()})
+    finally:
+        ops.attention_precision, ops.gemm_precision = old, oldg
+    d = H.maxdiff(out, ref)
+    agree = (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean().item()
+    magree = (rm["matches0"].cpu() == refm["matches0"]).float().mean().item()
+    print(f"C5 fp16 attention + GEMM: |logit - oracle| {d:.2e}, argmax agreement {agree:.4f}; gml index agreement {magree:.4f}")
+    assert d < 0.25 and agree >= 0.97 and magree >= 0.95
 
 
 def _gml(dev):
