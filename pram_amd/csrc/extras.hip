@@ -37,37 +37,48 @@ __global__ __launch_bounds__(256) void seg_epilogue_kernel(const float* __restri
                                                            int n_max, int c, float thr, float* __restrict__ scores_out,
                                                            int* __restrict__ seg_id, int* __restrict__ non_bg,
                                                            int* __restrict__ n_non_bg) {
+    __shared__ int s_cnt[4];
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int len = lens ? lens[b] : n_max;
-    if (n >= len) return;
-    const float* x = logits + ((size_t)b * n_max + n) * c;
-    float mx = -INFINITY;
-    int mi = 0x7fffffff;
-    for (int j = lane; j < c; j += 64) {
-        const float v = x[j];
-        if (v > mx) { mx = v; mi = j; }
-    }
+    int kept = 0;
+    // 16 tokens per workgroup (4 per wave): one atomic per workgroup instead of one per token
+    for (int it = 0; it < 4; ++it) {
+        const int n = blockIdx.x * 16 + it * 4 + wave;
+        if (n >= len) continue;           // wave-uniform
+        const float* x = logits + ((size_t)b * n_max + n) * c;
+        float mx = -INFINITY;
+        int mi = 0x7fffffff;
+        for (int j = lane; j < c; j += 64) {
+            const float v = x[j];
+            if (v > mx) { mx = v; mi = j; }
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(mx, o, 64);
-        const int oi = __shfl_xor(mi, o, 64);
-        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
-    }
-    float sum = 0.f;
-    for (int j = lane; j < c; j += 64) sum += expf(x[j] - mx);
-    sum = wave_sum(sum);
-    if (scores_out) {
-        float* so = scores_out + ((size_t)b * n_max + n) * c;
-        for (int j = lane; j < c; j += 64) so[j] = expf(x[j] - mx) / sum;
-    }
-    if (lane == 0) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mx, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+        }
+        float sum = 0.f;
+        for (int j = lane; j < c; j += 64) sum += expf(x[j] - mx);
+        sum = wave_sum(sum);
+        if (scores_out) {
+            float* so = scores_out + ((size_t)b * n_max + n) * c;
+            for (int j = lane; j < c; j += 64) so[j] = expf(x[j] - mx) / sum;
+        }
         const float bg = expf(x[0] - mx) / sum;
         const int keep = bg < thr;
-        seg_id[(size_t)b * n_max + n] = mi - 1;
-        non_bg[(size_t)b * n_max + n] = keep;
-        if (keep) atomicAdd(&n_non_bg[b], 1);
+        kept += keep;
+        if (lane == 0) {
+            seg_id[(size_t)b * n_max + n] = mi - 1;
+            non_bg[(size_t)b * n_max + n] = keep;
+        }
+    }
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (tot) atomicAdd(&n_non_bg[b], tot);
     }
 }
 
@@ -206,7 +217,7 @@ extern "C" int pram_seg_epilogue_f32(const float* logits, const int* lens, int b
         pram_set_error("pram_seg_epilogue_f32: memset failed");
         return PRAM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(seg_epilogue_kernel, dim3(cdiv(n_max, 4), batch), dim3(256), 0, st, logits, lens, n_max, n_class,
+    hipLaunchKernelGGL(seg_epilogue_kernel, dim3(cdiv(n_max, 16), batch), dim3(256), 0, st, logits, lens, n_max, n_class,
                        bg_threshold, seg_scores, seg_ids, non_bg_mask, n_non_bg);
     return pram_launch_status("pram_seg_epilogue_f32");
 }
