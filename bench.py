@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic query frames per GPU
+A "step" is one pass of the hot path over one batch of 16 synthetic query frames per GPU
 (SFD2 extract + sample -> SegNetViT nc113 -> GML match with 20 Sinkhorn iterations against a
 2048-keypoint reference set), inputs resident in HBM.  Queries shard across ranks with no data-path
 collective; each step ends with the single all-gather of the fixed-size result records.
@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=8, help="queries per GPU per step (C3: 64 over 8 GPUs)")
+    ap.add_argument("--batch-per-gpu", type=int, default=16,
+                    help="queries per GPU per step (BASELINE configs[1]: batch = 16 on one MI355X; weak scaling keeps it per GPU)")
     ap.add_argument("--kpts", type=int, default=2048)
     ap.add_argument("--n-class", type=int, default=113, help="landmark classes (7Scenes 113, Cambridge 161, Aachen 513)")
     ap.add_argument("--matcher", default="gml", choices=["gml", "adagml"])
@@ -208,7 +209,7 @@ def main():
         attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic = None
-    if (args.kpts, B, args.matcher, args.stages, args.n_class, ops.attention_precision) == (2048, 8, "gml", "erm", 113, "f32") and ops.gemm_precision == "f32":
+    if (args.kpts, B, args.matcher, args.stages, args.n_class, ops.attention_precision) == (2048, 16, "gml", "erm", 113, "f32") and ops.gemm_precision == "f32":
         try:   # HBM bytes per attention launch of THIS configuration, from the committed rocprofv3 --pmc passes
             traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
         except Exception:

@@ -122,6 +122,7 @@ class PackedCache:
 
     def _packed_invalidate(self):
         self.__dict__.setdefault("_packed_store", {}).clear()
+        ops._w16_cache.clear()      # fp16 weight copies are keyed by device address: drop them with their sources
 
     def _apply(self, fn, *a, **k):  # .to/.cuda/.float
         r = super()._apply(fn, *a, **k)
