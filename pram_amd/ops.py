@@ -55,6 +55,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
     if residual is not None:
         residual = residual.contiguous()
+    if m == 0:          # empty token set: nothing to launch (an empty tensor has a null data pointer)
+        return out
     flags, rc, rs, rcols = 0, None, None, 0
     if rotary is not None:
         rc, rs, rcols = rotary
