@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--matcher", default="gml", choices=["gml", "adagml"])
     ap.add_argument("--stages", default="erm", help="e=extract r=recognise m=match")
     ap.add_argument("--cpu-queries", type=int, default=4, help="CPU-baseline sample size (0 = skip)")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16"],
+                    help="f32 (default, the parity configuration) or f16 = BASELINE C5 'fp16 MFMA path' (fp16 operands, "
+                         "fp32 accumulate) for attention, token GEMMs and convolutions; own tolerance, not the headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,6 +162,8 @@ def main():
 
     from pram_amd import ops, weights as Wt
     from pram_amd.pipeline import QueryPipeline, gather_records
+    if args.precision:
+        ops.attention_precision = ops.gemm_precision = args.precision
     sfd2, seg, matcher, sds = build_models(dev, args.matcher, args.n_class)
     pipe = QueryPipeline(sfd2, seg, matcher, max_keypoints=args.kpts, min_keypoints=128)
 

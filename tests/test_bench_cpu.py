@@ -1,0 +1,35 @@
+"""CPU: bench.py plumbing that does not need the GPU — CLI contract, core detection, and the refusal to run
+without an MI355X (there is no CPU fallback to time by accident)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_bench_refuses_without_gpu():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)
+
+
+def test_bench_cli_contract_and_cores():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert 1 <= bench.usable_cores() <= 4096
+    src = (ROOT / "bench.py").read_text()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in src
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"',
+                '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
+
+
+def test_committed_bench_line_is_well_formed():
+    line = json.loads((ROOT / "profiles" / "r01_bench_final.json").read_text())
+    assert line["unit"] == "queries/s" and line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["peak"] == 157.3
+    assert abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.05          # no over-fetch
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
