@@ -12,6 +12,10 @@ Weight packing (done once per device, cached by the owning module):
     epilogue rotates lane-locally (PRAM_LIN_ROTARY).
   * cross attention: ``to_qk`` and ``to_v`` are stacked into one [512,256] projection; the
     reference's two dh^-1/4 factors (nets/gml.py:174) are applied as one dh^-1/2 score scale.
+  * ``proj`` is folded into ``mlp.0`` (inference-time weight folding, like the BatchNorm fold):
+    mlp.0(cat[x, proj(ctx)]) = W0a x + (W0b Wp) ctx + (b0 + W0b bp), products formed once in fp64.
+    One 256x256 GEMM and one [tokens,256] round trip per block disappear; results move by ~1e-7
+    relative (covered by the same parity tests).
 """
 from __future__ import annotations
 
@@ -30,6 +34,17 @@ def _rot_perm() -> torch.Tensor:
     return torch.cat([d[0::2], d[1::2]])
 
 
+def _fold_proj_into_mlp0(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
+    """-> {'mlp0_w' [2h, 2h], 'mlp0_b' [2h]} acting on cat[x, ctx] (ctx = attention output, before proj)."""
+    w0 = sd[prefix + ".mlp.0.weight"].detach().double().cpu()
+    b0 = sd[prefix + ".mlp.0.bias"].detach().double().cpu()
+    wp = sd[prefix + ".proj.weight"].detach().double().cpu()
+    bp = sd[prefix + ".proj.bias"].detach().double().cpu()
+    hid = wp.shape[0]
+    w0a, w0b = w0[:, :w0.shape[1] - hid], w0[:, w0.shape[1] - hid:]
+    return {"mlp0_w": torch.cat([w0a, w0b @ wp], 1).float(), "mlp0_b": (b0 + w0b @ bp).float()}
+
+
 def pack_self_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[str, torch.Tensor]:
     w = sd[prefix + ".qkv.weight"].detach().float()
     b = sd[prefix + ".qkv.bias"].detach().float()
@@ -41,9 +56,8 @@ def pack_self_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[st
     bq, bk, bv = b[:, perm, 0], b[:, perm, 1], b[:, :, 2]
     wp = torch.cat([wq.reshape(hid, -1), wk.reshape(hid, -1), wv.reshape(hid, -1)], 0)
     bp = torch.cat([bq.reshape(hid), bk.reshape(hid), bv.reshape(hid)], 0)
-    out = {"qkv_w": wp, "qkv_b": bp}
-    for k in ("proj.weight", "proj.bias", "mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias",
-              "mlp.3.weight", "mlp.3.bias"):
+    out = {"qkv_w": wp, "qkv_b": bp, **_fold_proj_into_mlp0(sd, prefix)}
+    for k in ("mlp.1.weight", "mlp.1.bias", "mlp.3.weight", "mlp.3.bias"):
         out[k] = sd[f"{prefix}.{k}"].detach().float()
     return {k: v.contiguous().to(device) for k, v in out.items()}
 
@@ -53,16 +67,15 @@ def pack_cross_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[s
         "qkv_w": torch.cat([sd[prefix + ".to_qk.weight"], sd[prefix + ".to_v.weight"]], 0).detach().float(),
         "qkv_b": torch.cat([sd[prefix + ".to_qk.bias"], sd[prefix + ".to_v.bias"]], 0).detach().float(),
     }
-    for k in ("proj.weight", "proj.bias", "mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias",
-              "mlp.3.weight", "mlp.3.bias"):
+    out.update(_fold_proj_into_mlp0(sd, prefix))
+    for k in ("mlp.1.weight", "mlp.1.bias", "mlp.3.weight", "mlp.3.bias"):
         out[k] = sd[f"{prefix}.{k}"].detach().float()
     return {k: v.contiguous().to(device) for k, v in out.items()}
 
 
 def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106)"""
-    msg = ops.linear(ctx, p["proj.weight"], p["proj.bias"])
-    h = ops.linear(x, p["mlp.0.weight"], p["mlp.0.bias"], x2=msg)
+    """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0"""
+    h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx)
     ops.layernorm_gelu_(h, p["mlp.1.weight"], p["mlp.1.bias"])
     return ops.linear(h, p["mlp.3.weight"], p["mlp.3.bias"], residual=x)
 

@@ -99,8 +99,9 @@ def test_qkv_rotary_epilogue(dev):
     B, N = 2, 200
     x = rnd(2, "rot/x", (B, N, 256))
     sd = {"p.qkv.weight": rnd(2, "rot/w", (768, 256), 1 / 16.0), "p.qkv.bias": rnd(2, "rot/b", (768,), 0.1)}
-    for k in ("proj.weight", "proj.bias", "mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias", "mlp.3.weight", "mlp.3.bias"):
-        sd["p." + k] = torch.zeros(1)
+    sd.update({"p.proj.weight": torch.zeros(256, 256), "p.proj.bias": torch.zeros(256), "p.mlp.0.weight": torch.zeros(512, 512),
+               "p.mlp.0.bias": torch.zeros(512), "p.mlp.1.weight": torch.ones(512), "p.mlp.1.bias": torch.zeros(512),
+               "p.mlp.3.weight": torch.zeros(256, 512), "p.mlp.3.bias": torch.zeros(256)})
     kp = torch.stack([W.synthetic_tokens(0, N)[1], W.synthetic_tokens(1, N)[1]])
     Wr = rnd(2, "rot/wr", (32, 2))
     cos_r, sin_r = R.fourier_encoding(Wr, R.normalize_keypoints(kp, (1, 3, 480, 640)))

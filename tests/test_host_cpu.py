@@ -53,8 +53,9 @@ def test_weights_deterministic():
 def test_qkv_packing_is_a_permutation():
     from pram_amd.nets import _blocks as blk
     sd = {"p.qkv.weight": torch.arange(768 * 256, dtype=torch.float32).view(768, 256), "p.qkv.bias": torch.arange(768, dtype=torch.float32)}
-    for k in ("proj.weight", "proj.bias", "mlp.0.weight", "mlp.0.bias", "mlp.1.weight", "mlp.1.bias", "mlp.3.weight", "mlp.3.bias"):
-        sd["p." + k] = torch.zeros(1)
+    sd.update({"p.proj.weight": torch.zeros(256, 256), "p.proj.bias": torch.zeros(256), "p.mlp.0.weight": torch.zeros(512, 512),
+               "p.mlp.0.bias": torch.zeros(512), "p.mlp.1.weight": torch.ones(512), "p.mlp.1.bias": torch.zeros(512),
+               "p.mlp.3.weight": torch.zeros(256, 512), "p.mlp.3.bias": torch.zeros(256)})
     pk = blk.pack_self_block(sd, "p", "cpu")
     assert sorted(pk["qkv_b"].tolist()) == list(range(768))
     # head 1, q, packed column 3 = original even dim 6 -> row 1*192 + 6*3 + 0
