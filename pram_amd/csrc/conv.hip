@@ -104,41 +104,39 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
 
     // loaders: clamped (always legal) addresses + select, no branches around the loads
     const int nlast = p.cout - 1, klast = p.k - 4, ntap = p.ks * p.ks;
-    auto tap_of = [&](int kt, int& tap, int& ci) {
+    // Wave-uniform walk over K = (ky, kx, ci): advanced incrementally once per chunk (no integer divisions in the loop).
+    // CIN4 (conv1a): a chunk spans 8 taps, one per staging column, so the tap is per-thread (tap = 8 kt + skq <= 15).
+    int cky = 0, ckx = 0, cci = 0;
+    auto adv = [&](int kt) {
         if (CIN4) {
-            tap = kt * 8 + skq;   // one tap (4 padded channels) per float4
-            ci = 0;
+            const int tap = kt * 8 + skq;
+            cky = (tap * 11) >> 5;            // tap / 3 for tap < 16
+            ckx = tap - cky * 3;
+            cci = 0;
+        } else if (kt == 0) {
+            cky = ckx = cci = 0;
         } else {
-            const int k = kt * BK;
-            tap = k / p.cin;      // cin % 32 == 0: a chunk never straddles taps (wave-uniform)
-            ci = k - tap * p.cin + skq * 4;
+            cci += BK;
+            if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
         }
     };
+    const float* brow[C::PB];
+#pragma unroll
+    for (int pp = 0; pp < C::PB; ++pp) brow[pp] = p.w + (size_t)min(col0 + srow + 32 * pp, nlast) * p.k;
     auto la = [&](int pp, int kt) -> float4 {
-        int tap, ci;
-        tap_of(kt, tap, ci);
-        const int tc = min(tap, ntap - 1);
-        const int ky = tc / p.ks, kx = tc - ky * p.ks;
-        const int iyc = min(max(iy0[pp] + ky, 0), p.h - 1), ixc = min(max(ix0[pp] + kx, 0), p.wd - 1);
-        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + ci);
+        const int ky = min(cky, p.ks - 1);
+        const int iyc = min(max(iy0[pp] + ky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
+        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + (CIN4 ? 0 : skq * 4));
     };
     auto oka = [&](int pp, int kt) -> bool {
-        int tap, ci;
-        tap_of(kt, tap, ci);
-        const int tc = min(tap, ntap - 1);
-        const int ky = tc / p.ks, kx = tc - ky * p.ks;
-        const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
-        return ok[pp] && tap < ntap && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
+        return ok[pp] && cky < p.ks && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
-    auto lb = [&](int pp, int kt) -> float4 {
-        const int col = col0 + srow + 32 * pp;
-        const int k = kt * BK + skq * 4;
-        return *reinterpret_cast<const float4*>(p.w + (size_t)min(col, nlast) * p.k + min(k, klast));
-    };
+    auto lb = [&](int pp, int kt) -> float4 { return *reinterpret_cast<const float4*>(brow[pp] + min(kt * BK + skq * 4, klast)); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.cout && (kt * BK + skq * 4) < p.k; };
 
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, la, oka, lb, okb, (p.k + BK - 1) / BK, acc);
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (p.k + BK - 1) / BK, acc);
 
     conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
@@ -175,27 +173,27 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
     }
     const int nlast = p.cout - 1;
+    int cky = 0, ckx = 0, cci = 0;
+    auto adv = [&](int kt) {
+        if (kt == 0) { cky = ckx = cci = 0; return; }
+        cci += BK;
+        if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
+    };
+    const _Float16* brow16[C::PB];
+#pragma unroll
+    for (int pp = 0; pp < C::PB; ++pp) brow16[pp] = w16 + (size_t)min(col0 + brow + 32 * pp, nlast) * p.k + bsl * 8;
     auto la = [&](int pp, int kt) -> float4 {
-        const int k = kt * BK;
-        const int tap = k / p.cin;
-        const int ci = k - tap * p.cin + akq * 4;
-        const int ky = tap / p.ks, kx = tap - ky * p.ks;
-        const int iyc = min(max(iy0[pp] + ky, 0), p.h - 1), ixc = min(max(ix0[pp] + kx, 0), p.wd - 1);
-        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + ci);
+        const int iyc = min(max(iy0[pp] + cky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
+        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + akq * 4);
     };
     auto oka = [&](int pp, int kt) -> bool {
-        const int tap = (kt * BK) / p.cin;
-        const int ky = tap / p.ks, kx = tap - ky * p.ks;
-        const int iy = iy0[pp] + ky, ix = ix0[pp] + kx;
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
         return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
-    auto lb = [&](int pp, int kt) -> uint4 {
-        const int cc = min(col0 + brow + 32 * pp, nlast);
-        return *reinterpret_cast<const uint4*>(w16 + (size_t)cc * p.k + kt * BK + bsl * 8);
-    };
+    auto lb = [&](int pp, int kt) -> uint4 { return *reinterpret_cast<const uint4*>(brow16[pp] + kt * BK); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 32 * pp) < p.cout; };
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, la, oka, lb, okb, p.k / BK, acc);
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, acc);
     conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 

@@ -56,8 +56,10 @@ __device__ __forceinline__ float4 zero_unless(float4 v, bool ok) {
 
 // ALoad: float4 operator()(int p, int kt) -> raw A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3]; AOk: its predicate.
 // BLoad / BOk: same for the weight rows.
-template <int MI, int WN, class ALoad, class AOk, class BLoad, class BOk>
-__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+// Adv(kt) is called once per chunk before its loads: wave-uniform loader state (e.g. the convolution's current
+// tap / channel offset) advances incrementally there instead of being re-derived with integer divisions per load.
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
                                          f32x16 (&acc)[MI][2]) {
     using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
@@ -74,6 +76,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, B
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     float4 ra[C::PA], rb[C::PB];
+    adv(0);
 #pragma unroll
     for (int p = 0; p < C::PA; ++p) ra[p] = la(p, 0);
 #pragma unroll
@@ -88,6 +91,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, B
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
+            adv(kt + 1);
 #pragma unroll
             for (int p = 0; p < C::PA; ++p) ra[p] = la(p, kt + 1);
 #pragma unroll

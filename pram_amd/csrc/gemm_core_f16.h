@@ -36,8 +36,8 @@ __device__ __forceinline__ int swz(int slot, int row) { return slot ^ ((row >> 1
 
 // ALoad(p, kt) -> raw float4 A[row = tid/16 + 16p][kt*64 + (tid%16)*4 ..+3];  AOk(p, kt) its predicate
 // BLoad(p, kt) -> raw uint4  W[col = tid/8 + 32p][kt*64 + (tid%8)*8 ..+7] (fp16); BOk(p, kt) its predicate
-template <int MI, int WN, class ALoad, class AOk, class BLoad, class BOk>
-__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
                                          f32x16 (&acc)[MI][2]) {
     using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
@@ -74,6 +74,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, B
             *reinterpret_cast<uint4*>(&s.b[buf][row * BK + swz(bsl, row) * 8]) = v;
         }
     };
+    adv(0);
 #pragma unroll
     for (int p = 0; p < C::PA; ++p) ra[p] = la(p, 0);
 #pragma unroll
@@ -85,6 +86,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, ALoad& la, AOk& oka, B
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
+            adv(kt + 1);
 #pragma unroll
             for (int p = 0; p < C::PA; ++p) ra[p] = la(p, kt + 1);
 #pragma unroll

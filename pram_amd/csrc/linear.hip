@@ -112,26 +112,31 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
     const int srow = tid >> 3, skq = tid & 7;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // loaders: clamped (always legal) addresses + select, no branches around the loads
+    // loaders: clamped (always legal) addresses + select, no branches around the loads; row bases hoisted
     const int mlast = p.m - 1, nlast = p.n - 1, klast = K - 4;
+    const float* arow0[C::PA];
+    const float* arow1[C::PA];
+    const float* brow[C::PB];
+#pragma unroll
+    for (int pp = 0; pp < C::PA; ++pp) {
+        const int rc = min(row0 + srow + 32 * pp, mlast);
+        arow0[pp] = a0 + (size_t)rc * p.lda0;
+        arow1[pp] = p.a1 ? p.a1 + (size_t)rc * p.lda1 - p.k0 : arow0[pp];
+    }
+#pragma unroll
+    for (int pp = 0; pp < C::PB; ++pp) brow[pp] = w + (size_t)min(col0 + srow + 32 * pp, nlast) * K;
+    auto adv = [](int) {};
     auto la = [&](int pp, int kt) -> float4 {
-        const int row = row0 + srow + 32 * pp;
-        const int k = kt * BK + skq * 4;
-        const int rc = min(row, mlast), kc = min(k, klast);
+        const int kc = min(kt * BK + skq * 4, klast);
         const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
-        const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (a0 + (size_t)rc * p.lda0 + kc);
-        return *reinterpret_cast<const float4*>(src);
+        return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
     };
     auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + 32 * pp) < p.m && (kt * BK + skq * 4) < K; };
-    auto lb = [&](int pp, int kt) -> float4 {
-        const int col = col0 + srow + 32 * pp;
-        const int k = kt * BK + skq * 4;
-        return *reinterpret_cast<const float4*>(w + (size_t)min(col, nlast) * K + min(k, klast));
-    };
+    auto lb = [&](int pp, int kt) -> float4 { return *reinterpret_cast<const float4*>(brow[pp] + min(kt * BK + skq * 4, klast)); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.n && (kt * BK + skq * 4) < K; };
 
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
 
     linear_epilogue<MI, WN>(p, acc, out, row0, col0, BM, BN);
 }
@@ -165,8 +170,9 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
         return *reinterpret_cast<const uint4*>(w16 + (size_t)cc * K + kc);
     };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 32 * pp) < p.n && (kt * BK + bsl * 8) < K; };
+    auto adv = [](int) {};
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
     linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
 }
 

@@ -161,5 +161,21 @@ class GML(blk.PackedCache, nn.Module):
         return sink_algorithm(dist, dustbin, iteration) if self.with_sinkhorn else dual_softmax(dist, dustbin)
 
     def compute_matches(self, scores, p=0.2):
-        raise NotImplementedError("compute_matches is fused into the last Sinkhorn pass (ops.sinkhorn_match); "
-                                  "it never sees a materialised score matrix on the GPU path")
+        """nets/gml.py:304-319 on a materialised [B, M+1, N+1] score matrix (API parity; produce_matches itself
+        uses the match extraction fused into the last Sinkhorn pass).  Row / column arg-max by the wave-reduction
+        top-2 kernel (first occurrence on ties, like torch.max)."""
+        blk.require_cuda(scores, "GML.compute_matches")
+        inner = scores[:, :-1, :-1].float().contiguous()
+        max0, _, indices0 = ops.row_top2(inner, largest=True)
+        max1, _, indices1 = ops.row_top2(inner.transpose(1, 2).contiguous(), largest=True)
+        ar0 = torch.arange(indices0.shape[1], device=scores.device)[None]
+        ar1 = torch.arange(indices1.shape[1], device=scores.device)[None]
+        mutual0 = ar0 == indices1.gather(1, indices0)
+        mutual1 = ar1 == indices0.gather(1, indices1)
+        zero = scores.new_tensor(0)
+        mscores0 = torch.where(mutual0, max0, zero)
+        mscores1 = torch.where(mutual1, mscores0.gather(1, indices1), zero)
+        valid0 = mutual0 & (mscores0 > p)
+        valid1 = mutual1 & valid0.gather(1, indices1)
+        return (torch.where(valid0, indices0, indices0.new_tensor(-1)), torch.where(valid1, indices1, indices1.new_tensor(-1)),
+                mscores0, mscores1)

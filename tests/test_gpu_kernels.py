@@ -253,6 +253,16 @@ def test_sinkhorn_2049(dev):
     assert (i0 >= 0).sum() > 500
 
 
+def test_compute_matches_api(dev, golden):
+    """GML.compute_matches on a materialised score matrix == the reference's outputs (golden)."""
+    from pram_amd.nets.gml import GML
+    g = golden("sinkhorn_257x193")
+    net = GML({})
+    i0, i1, s0, s1 = net.compute_matches(torch.from_numpy(g["p"]).to(dev), p=0.2)
+    assert np.array_equal(i0.cpu().numpy(), g["m0_p02"]) and np.array_equal(i1.cpu().numpy(), g["m1_p02"])
+    assert np.abs(s0.cpu().numpy() - g["s0"]).max() < 1e-7 and np.abs(s1.cpu().numpy() - g["s1"]).max() < 1e-7
+
+
 def test_argmax_ties_lowest_index(dev):
     from pram_amd import ops
     M = torch.zeros(1, 6, 8)
