@@ -220,6 +220,36 @@ def gen_adagml(ref):
              conf0_l1=probes["conf0_1"].numpy())
 
 
+def gen_adagml_run(ref):
+    """AdaGML.run (mode=1): normalised keypoints packed in x, returns matched original ids."""
+    print("AdaGML.run")
+    a = ref["adagml"]
+    net = a.AdaGML({}).eval()
+    sd = W.make_state_dict("adagml", net.state_dict(), seed=7)
+    net.load_state_dict(sd, strict=True)
+    pair = W.synthetic_match_pair(6, 400, 360)
+    nk0 = R.normalize_keypoints(pair["keypoints0"], (1, 3, 640, 480))
+    nk1 = R.normalize_keypoints(pair["keypoints1"], (1, 3, 640, 480))
+    data = {"desc1": pair["descriptors0"][None], "desc2": pair["descriptors1"][None],
+            "x1": torch.cat([nk0, pair["scores0"][:, None]], -1)[None], "x2": torch.cat([nk1, pair["scores1"][:, None]], -1)[None]}
+    with torch.no_grad():
+        r = net(data, mode=1)
+        o = R.adagml_run(sd, data)
+    assert torch.equal(r["index0"], o["index0"]) and torch.equal(r["index1"], o["index1"])
+    # tiny-set guard: biases that prune almost everything
+    sd2 = dict(sd)
+    for k in list(sd2):
+        if k.endswith("predict.3.bias"):
+            sd2[k] = torch.tensor([-20.0])
+    net.load_state_dict(sd2, strict=True)
+    with torch.no_grad():
+        r2 = net(data, mode=1)
+        o2 = R.adagml_run(sd2, data)
+    assert torch.equal(r2["index0"], o2["index0"]) and r2["index0"].tolist() == [0]
+    print(f"  run: {len(r['index0'])} matches; tiny-set guard returns zeros")
+    save("adagml_run_m400_n360", index0=r["index0"].numpy().astype(np.int32), index1=r["index1"].numpy().astype(np.int32))
+
+
 def gen_normalize(ref):
     print("normalize_keypoints (W,H)-swap quirk")
     k = torch.tensor([[[0.0, 0.0], [320.0, 240.0], [639.0, 479.0]]])
@@ -439,7 +469,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
-    only = sys.argv[1:] or ["schema", "normalize", "sinkhorn", "segnetvit", "gml", "adagml", "sfd2", "edges"]
+    only = sys.argv[1:] or ["schema", "normalize", "sinkhorn", "segnetvit", "gml", "adagml", "adagml_run", "sfd2", "edges"]
     for name in only:
         globals()[f"gen_{name}"](ref)
     print("all reference-vs-oracle checks passed; fixtures written to", OUT)

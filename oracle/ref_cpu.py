@@ -315,6 +315,43 @@ def adagml_produce_matches(sd: SD, data: dict, p: float = 0.2, n_layers: int = 9
     return {"matches0": full_i, "matching_scores0": full_s}
 
 
+def adagml_run(sd: SD, data: dict, p: float = 0.2, n_layers: int = 9, n_min_tokens: int = 256, sinkhorn_iterations: int = 20) -> dict:
+    """AdaGML.run — nets/adagml.py:406-489: pre-normalised keypoints in x[:, :, :2], B = 1, returns matched original ids."""
+    d0 = _lin(sd, "input_proj", data["desc1"])
+    d1 = _lin(sd, "input_proj", data["desc2"])
+    c0, s0 = fourier_encoding(sd["poseenc.Wr.weight"], data["x1"][:, :, :2])
+    c1, s1 = fourier_encoding(sd["poseenc.Wr.weight"], data["x2"][:, :, :2])
+    m, n = d0.shape[1], d1.shape[1]
+    ind0, ind1 = torch.arange(m), torch.arange(n)
+    ni = 0
+    for ni in range(n_layers):
+        d0, a00 = self_block(sd, f"self_attn.{ni}", d0, c0, s0, want_colmean=True)
+        d1, a11 = self_block(sd, f"self_attn.{ni}", d1, c1, s1, want_colmean=True)
+        d0, d1, a01, a10 = cross_block(sd, f"cross_attn.{ni}", d0, d1, want_colmean=True)
+        conf0 = pooling_layer(sd, f"pooling.{ni}", d0, torch.stack([a00, a01], -1)).squeeze(-1)
+        conf1 = pooling_layer(sd, f"pooling.{ni}", d1, torch.stack([a11, a10], -1)).squeeze(-1)
+        if ni >= 1:
+            thr = adagml_confidence_threshold(ni, n_layers)
+            if d0.shape[1] >= n_min_tokens:
+                k0 = conf0[0] > thr
+                ind0, d0, c0, s0 = ind0[k0], d0[:, k0], c0[:, k0], s0[:, k0]
+            if d1.shape[1] >= n_min_tokens:
+                k1 = conf1[0] > thr
+                ind1, d1, c1, s1 = ind1[k1], d1[:, k1], c1[:, k1], s1[:, k1]
+            if d0.shape[1] <= 5 or d1.shape[1] <= 5:
+                return {"index0": torch.zeros(1).long(), "index1": torch.zeros(1).long()}
+            conf = torch.cat([conf0, conf1], -1)
+            if 1.0 - (conf < thr).float().sum() / (m + n) > 0.95:
+                break
+    dim = d0.shape[-1]
+    md0 = _lin(sd, f"out_proj.{ni}", d0) / dim ** 0.25
+    md1 = _lin(sd, f"out_proj.{ni}", d1) / dim ** 0.25
+    score = sink_algorithm(torch.einsum("bmd,bnd->bmn", md0, md1), sd["bin_score"], sinkhorn_iterations)
+    i0, _, _, _ = compute_matches(score, p)
+    valid = i0[0] > -1
+    return {"index0": ind0[valid], "index1": ind1[i0[0][valid]]}
+
+
 # ------------------------------------------------------------------------------------------
 # SFD2 — nets/sfd2.py
 # ------------------------------------------------------------------------------------------

@@ -71,8 +71,30 @@ class AdaGML(GML):
         if not self.training:
             if mode == 0:
                 return self.produce_matches(data=data)
-            raise NotImplementedError("AdaGML.run (training-time evaluation helper, nets/adagml.py:406-489) is outside the hot path")
+            return self.run(data=data)
         raise NotImplementedError("training is outside the hot path")
+
+    @torch.no_grad()
+    def run(self, data, p=0.2):
+        """AdaGML.run (nets/adagml.py:406-489): the evaluation-time entry with pre-normalised keypoints packed as
+        x = [kx, ky, ..., score]; returns the matched ORIGINAL indices {'index0', 'index1'} of one pair (B = 1), or
+        two zero tensors when pruning leaves <= 5 tokens in a set (adagml.py:458-462)."""
+        d = {'descriptors0': data['desc1'], 'descriptors1': data['desc2'],
+             'keypoints0': data['x1'][:, :, :2], 'keypoints1': data['x2'][:, :, :2],
+             'norm_keypoints0': data['x1'][:, :, :2].contiguous(), 'norm_keypoints1': data['x2'][:, :, :2].contiguous(),
+             'scores0': data['x1'][:, :, -1], 'scores1': data['x2'][:, :, -1]}
+        assert d['descriptors0'].shape[0] == 1, "AdaGML.run is a B = 1 API in the reference"
+        internal = {}
+        self.produce_matches(d, p=p, _internal=internal)
+        dev = d['descriptors0'].device
+        if bool(internal['tiny'][0].item()):
+            z = torch.zeros(size=(1,), device=dev).long()
+            return {'index0': z, 'index1': z.clone()}
+        n0 = int(internal['lens'][0].item())
+        m0 = internal['matches0'][0, :n0]
+        valid = m0 > -1
+        ind0, ind1 = internal['ind'][0].long(), internal['ind'][1].long()
+        return {'index0': ind0[:n0][valid], 'index1': ind1[m0[valid]]}
 
     def confidence_threshold(self, layer_index: int):
         """nets/adagml.py:516-520"""
@@ -99,6 +121,7 @@ class AdaGML(GML):
         blk.require_cuda(desc0, "AdaGML.produce_matches")
         _ = data['scores0'], data['scores1']     # read like the reference (KeyError if absent), unused in compute
         probes = kwargs.get('probes')
+        internal = kwargs.get('_internal')
         (k0, cx0, cy0, sc0), (k1, cx1, cy1, sc1) = normalize_inputs(data)
         P = self._packed_get(self._build_packed)
         B, m, _ = desc0.shape
@@ -121,6 +144,7 @@ class AdaGML(GML):
                           l1.int() if l1 is not None else torch.full((B,), n, device=dev, dtype=torch.int32)]).contiguous()
         num_points = (lens[:B] + lens[B:]).float()            # m + n of the ORIGINAL sets (adagml.py:370)
         active = torch.ones(B, device=dev, dtype=torch.bool)
+        tiny = torch.zeros(B, device=dev, dtype=torch.bool)        # run(): a still-active pair was pruned to <= 5 tokens
         stop_layer = torch.full((B,), -1, device=dev, dtype=torch.int32)
         d = self.config['hidden_dim']
         md_final = torch.zeros(2 * B, T, d, device=dev, dtype=torch.float32)
@@ -142,6 +166,7 @@ class AdaGML(GML):
                     logit, thr, self.n_min_tokens, lens_eff, x.view(2 * B, T, -1), cos, sin, ind, want_conf=probes is not None)
                 x = x3.view(2 * B * T, -1)
                 lens = torch.where(active.repeat(2), lens_new, lens)
+                tiny = tiny | (active & ((lens[:B] <= 5) | (lens[B:] <= 5)))
                 if probes is not None:
                     probes[f"conf_{ni}"] = conf
                 # check_if_stop (adagml.py:522-531): 1 - #(conf < thr) / (m + n) > 0.95, same fp32 arithmetic
@@ -167,4 +192,6 @@ class AdaGML(GML):
                                           ind_final[B:].contiguous(), lf0, m)
         if probes is not None:
             probes.update(stop_layer=stop_layer, ind=ind_final, lens=lens_final)
+        if internal is not None:
+            internal.update(matches0=r['matches0'], ind=ind_final, lens=lens_final, tiny=tiny, stop_layer=stop_layer)
         return {'matches0': out_m, 'matching_scores0': out_s}

@@ -230,6 +230,24 @@ def test_adagml_early_stop_vs_oracle(dev):
     assert H.maxdiff(r["matching_scores0"], o["matching_scores0"]) < 1e-3
 
 
+def test_adagml_run_mode(dev, golden):
+    """AdaGML.forward(data, mode=1) == AdaGML.run: matched original ids vs the reference (golden) + the <= 5 token guard."""
+    from tests.test_oracle_golden import _run_inputs
+    from pram_amd.nets.adagml import AdaGML
+    g = golden("adagml_run_m400_n360")
+    data = {k: v.to(dev) for k, v in _run_inputs().items()}
+    r = _adagml(dev)(data, mode=1)
+    assert np.array_equal(r["index0"].cpu().numpy(), g["index0"]) and np.array_equal(r["index1"].cpu().numpy(), g["index1"])
+    sd = dict(H.adagml_sd())
+    for k in list(sd):
+        if k.endswith("predict.3.bias"):
+            sd[k] = torch.tensor([-20.0])
+    net = AdaGML({})
+    net.load_state_dict(sd, strict=True)
+    r2 = net.to(dev).eval().run(data)
+    assert r2["index0"].tolist() == [0] and r2["index1"].tolist() == [0]
+
+
 def test_adagml_batch_equals_single(dev):
     """B = 3 pairs of different difficulty in one device-resident call == three B = 1 calls (stop layers differ)."""
     net = _adagml(dev)

@@ -87,6 +87,20 @@ def test_adagml_golden(golden):
         assert np.array_equal(probes["ind0"].numpy(), g["ind0"]) and np.array_equal(probes["ind1"].numpy(), g["ind1"])
 
 
+def _run_inputs():
+    pair = W.synthetic_match_pair(6, 400, 360)
+    nk0 = R.normalize_keypoints(pair["keypoints0"], (1, 3, 640, 480))
+    nk1 = R.normalize_keypoints(pair["keypoints1"], (1, 3, 640, 480))
+    return {"desc1": pair["descriptors0"][None], "desc2": pair["descriptors1"][None],
+            "x1": torch.cat([nk0, pair["scores0"][:, None]], -1)[None], "x2": torch.cat([nk1, pair["scores1"][:, None]], -1)[None]}
+
+
+def test_adagml_run_golden(golden):
+    g = golden("adagml_run_m400_n360")
+    o = R.adagml_run(H.adagml_sd(), _run_inputs())
+    assert np.array_equal(o["index0"].numpy(), g["index0"]) and np.array_equal(o["index1"].numpy(), g["index1"])
+
+
 def test_adagml_empty_set_raises_like_reference():
     """SURVEY.md §3.4 edge case: un-calibrated pooling prunes a set to zero tokens; the reference raises
     IndexError from compute_matches (nets/adagml.py:500) and so does the restatement."""
