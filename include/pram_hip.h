@@ -98,6 +98,20 @@ int pram_attention_f16_f32(const float* q, int ldq, const float* k, int ldk, con
                            float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens,
                            int batch, int heads, int m_max, int n_max, float scale, void* stream);
 
+/* Both directions of CrossMultiHeadAttention.forward (nets/gml.py:175-179; adagml.py:222-231) in ONE launch:
+ * 2*pairs sequences of t_max rows each, sequences 0..pairs-1 = set 0, pairs..2*pairs-1 = set 1; sequence s takes
+ * its queries from rows s*t_max.. of qk (the shared to_qk projection) and its keys / values from sequence
+ * (s + pairs) mod 2*pairs of qk / v.  lens [2*pairs] (optional).  Per sequence the arithmetic is exactly
+ * pram_attention_f32's (same kernel, same tiling), so the result equals two separate calls bit for bit. */
+int pram_attention_cross_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
+                             const int* lens, int pairs, int heads, int t_max, float scale, void* stream);
+int pram_attention_cross_f16_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
+                                 const int* lens, int pairs, int heads, int t_max, float scale, void* stream);
+/* Column means for the same pairing: colmean [2*pairs][t_max]; row kb holds, per token of sequence kb, the mean
+ * over heads and over the queries of sequence (kb + pairs) mod 2*pairs (adagml.py:229). */
+int pram_attention_cross_colmean_f32(const float* qk, int ldqk, const float* lse2, float* colmean, const int* lens,
+                                     int pairs, int heads, int t_max, float scale, void* stream);
+
 /* Column means of the attention matrix (AdaGML Attention.forward nets/adagml.py:148,229; K10):
  *   colmean[b][j] = 1/(heads*m_b) * sum_h sum_i softmax(scale q k^T)[b,h,i,j] */
 int pram_attention_colmean_f32(const float* q, int ldq, const float* k, int ldk, const float* lse2,

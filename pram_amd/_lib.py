@@ -27,6 +27,9 @@ _SIGS = {
     "pram_attention_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P]),
     "pram_attention_f16_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P]),
     "pram_attention_colmean_f32": (I, [P, I, P, I, P, P, P, P, I, I, I, I, F, P]),
+    "pram_attention_cross_f32": (I, [P, I, P, I, P, I, P, P, I, I, I, F, P]),
+    "pram_attention_cross_f16_f32": (I, [P, I, P, I, P, I, P, P, I, I, I, F, P]),
+    "pram_attention_cross_colmean_f32": (I, [P, I, P, P, P, I, I, I, F, P]),
     "pram_sinkhorn_workspace_bytes": (SZ, [I, I, I]),
     "pram_sinkhorn_match_f32": (I, [P, I, P, P, P, I, F, P, I, P, P, P, P, I, I, I, P, P]),
     "pram_dual_softmax_match_f32": (I, [P, I, P, P, P, F, P, I, P, P, P, P, I, I, I, P, P]),

@@ -40,6 +40,7 @@ struct AttnArgs {
     int batch, heads, m_max, n_max;
     float scale2;
     int q_tiles;
+    int kv_shift;   // keys / values of batch element b come from element (b + kv_shift) % batch (cross attention: both directions in one launch)
 };
 
 struct Smem {
@@ -56,8 +57,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const int qt = id % p.q_tiles;
     const int bh = id / p.q_tiles;
     const int head = bh % p.heads, b = bh / p.heads;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
-    const int klen = p.k_lens ? p.k_lens[b] : p.n_max;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
     if (qt * BQ >= qlen || klen <= 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const bool q_ok = qrow < qlen;
 
     const float* qp = p.q + ((size_t)b * p.m_max + qrow) * p.ldq + head * D;
-    const float* kp = p.k + (size_t)b * p.n_max * p.ldk + head * D;
-    const float* vp = p.v + (size_t)b * p.n_max * p.ldv + head * D;
+    const float* kp = p.k + (size_t)kb * p.n_max * p.ldk + head * D;
+    const float* vp = p.v + (size_t)kb * p.n_max * p.ldv + head * D;
 
     // Q fragments: qf[c] = Q[qrow][8c + 4h .. +3]
     float4 qf[8];
@@ -248,13 +250,15 @@ struct ColArgs {
     const int* q_lens; const int* k_lens;
     int ldq, ldk, batch, heads, m_max, n_max;
     float scale2;
+    int kv_shift;   // as in AttnArgs; the means are written to the KEY side's row of colmean
 };
 
 __global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
     __shared__ float sq[BKV * D];
     const int b = blockIdx.y;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
-    const int klen = p.k_lens ? p.k_lens[b] : p.n_max;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int key0 = blockIdx.x * 128 + wave * 32;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
 
     for (int head = 0; head < p.heads; ++head) {
         const int key = key0 + r;
-        const float* kp = p.k + ((size_t)b * p.n_max + key) * p.ldk + head * D;
+        const float* kp = p.k + ((size_t)kb * p.n_max + key) * p.ldk + head * D;
         float4 kf[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         const int key = key0 + key_of(e, h);
-        if (r == 0 && key < klen) p.colmean[(size_t)b * p.n_max + key] = v * norm;
+        if (r == 0 && key < klen) p.colmean[(size_t)kb * p.n_max + key] = v * norm;
     }
 }
 
@@ -329,9 +333,21 @@ extern "C" int pram_attention_f32(const float* q, int ldq, const float* k, int l
     if (batch == 0 || m_max == 0) return PRAM_OK;
     PRAM_REQUIRE(n_max > 0, "pram_attention_f32: empty key set");
     AttnArgs p{q, k, v, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max, scale * LOG2E,
-               cdiv(m_max, BQ)};
+               cdiv(m_max, BQ), 0};
     hipLaunchKernelGGL(attention_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_f32");
+}
+
+extern "C" int pram_attention_cross_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
+                                        const int* lens, int pairs, int heads, int t_max, float scale, void* stream) {
+    PRAM_REQUIRE(qk && v && out, "pram_attention_cross_f32: null pointer");
+    PRAM_REQUIRE(ldqk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "pram_attention_cross_f32: ld must be a multiple of 4");
+    PRAM_REQUIRE(pairs >= 0 && heads > 0 && t_max >= 0, "pram_attention_cross_f32: bad sizes");
+    if (pairs == 0 || t_max == 0) return PRAM_OK;
+    AttnArgs p{qk, qk, v, out, lse2, lens, lens, ldqk, ldqk, ldv, ldo, 2 * pairs, heads, t_max, t_max, scale * LOG2E,
+               cdiv(t_max, BQ), pairs};
+    hipLaunchKernelGGL(attention_kernel, dim3(2 * pairs * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_cross_f32");
 }
 
 extern "C" int pram_attention_colmean_f32(const float* q, int ldq, const float* k, int ldk, const float* lse2,
@@ -340,7 +356,17 @@ extern "C" int pram_attention_colmean_f32(const float* q, int ldq, const float* 
     PRAM_REQUIRE(q && k && lse2 && colmean, "pram_attention_colmean_f32: null pointer");
     PRAM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0, "pram_attention_colmean_f32: ld must be a multiple of 4");
     if (batch == 0 || n_max == 0 || m_max == 0) return PRAM_OK;
-    ColArgs p{q, k, lse2, colmean, q_lens, k_lens, ldq, ldk, batch, heads, m_max, n_max, scale * LOG2E};
+    ColArgs p{q, k, lse2, colmean, q_lens, k_lens, ldq, ldk, batch, heads, m_max, n_max, scale * LOG2E, 0};
     hipLaunchKernelGGL(colmean_kernel, dim3(cdiv(n_max, 128), batch), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_colmean_f32");
+}
+
+extern "C" int pram_attention_cross_colmean_f32(const float* qk, int ldqk, const float* lse2, float* colmean, const int* lens,
+                                                int pairs, int heads, int t_max, float scale, void* stream) {
+    PRAM_REQUIRE(qk && lse2 && colmean, "pram_attention_cross_colmean_f32: null pointer");
+    PRAM_REQUIRE(ldqk % 4 == 0, "pram_attention_cross_colmean_f32: ld must be a multiple of 4");
+    if (pairs == 0 || t_max == 0) return PRAM_OK;
+    ColArgs p{qk, qk, lse2, colmean, lens, lens, ldqk, ldqk, 2 * pairs, heads, t_max, t_max, scale * LOG2E, pairs};
+    hipLaunchKernelGGL(colmean_kernel, dim3(cdiv(t_max, 128), 2 * pairs), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_cross_colmean_f32");
 }

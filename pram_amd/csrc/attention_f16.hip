@@ -36,6 +36,7 @@ struct Args {
     int batch, heads, m_max, n_max;
     float scale2;
     int q_tiles;
+    int kv_shift;   // as in attention.hip
 };
 
 struct alignas(16) Smem {
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256, 3) void attention_f16_kernel(Args p) {
     const int bh = id / p.q_tiles;
     const int head = bh % p.heads, b = bh / p.heads;
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
-    const int klen = p.k_lens ? p.k_lens[b] : p.n_max;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
     if (qt * BQ >= qlen || klen <= 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(256, 3) void attention_f16_kernel(Args p) {
     const bool q_ok = qrow < qlen;
 
     const float* qp = p.q + ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
-    const float* kp = p.k + (size_t)b * p.n_max * p.ldk + head * D;
-    const float* vp = p.v + (size_t)b * p.n_max * p.ldv + head * D;
+    const float* kp = p.k + (size_t)kb * p.n_max * p.ldk + head * D;
+    const float* vp = p.v + (size_t)kb * p.n_max * p.ldv + head * D;
 
     // Q fragments: qf[c][i] = fp16(Q[qrow][16c + 8h + i])
     half8 qf[4];
@@ -220,7 +222,18 @@ extern "C" int pram_attention_f16_f32(const float* q, int ldq, const float* k, i
     PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0, "pram_attention_f16_f32: bad sizes");
     if (batch == 0 || m_max == 0) return PRAM_OK;
     PRAM_REQUIRE(n_max > 0, "pram_attention_f16_f32: empty key set");
-    Args p{q, k, v, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ)};
+    Args p{q, k, v, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), 0};
     hipLaunchKernelGGL(attention_f16_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_f16_f32");
+}
+
+extern "C" int pram_attention_cross_f16_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
+                                            const int* lens, int pairs, int heads, int t_max, float scale, void* stream) {
+    PRAM_REQUIRE(qk && v && out, "pram_attention_cross_f16_f32: null pointer");
+    PRAM_REQUIRE(ldqk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "pram_attention_cross_f16_f32: ld must be a multiple of 4");
+    PRAM_REQUIRE(pairs >= 0 && heads > 0 && t_max >= 0, "pram_attention_cross_f16_f32: bad sizes");
+    if (pairs == 0 || t_max == 0) return PRAM_OK;
+    Args p{qk, qk, v, out, lse2, lens, lens, ldqk, ldqk, ldv, ldo, 2 * pairs, heads, t_max, t_max, scale * LOG2E, cdiv(t_max, BQ), pairs};
+    hipLaunchKernelGGL(attention_f16_kernel, dim3(2 * pairs * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_cross_f16_f32");
 }

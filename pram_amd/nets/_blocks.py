@@ -101,22 +101,15 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     (nets/gml.py:164-186): m0 = softmax_row(sim) v1, m1 = softmax_row(sim^T) v0."""
     hid = HEADS * DH
     qkv = ops.linear(x, p["qkv_w"], p["qkv_b"])          # [2B*T, 512] = [qk | v]
-    half = B * T
-    qk0, qk1 = qkv[:half, :hid], qkv[half:, :hid]
-    v0, v1 = qkv[:half, hid:], qkv[half:, hid:]
-    l0 = lens[:B] if lens is not None else None
-    l1 = lens[B:] if lens is not None else None
+    qk, v = qkv[:, :hid], qkv[:, hid:]
     scale = DH ** -0.5     # (dh^-1/4)^2
-    ctx = torch.empty(2 * half, hid, device=x.device, dtype=torch.float32)
+    # one launch for both directions: sequence s attends to sequence (s + B) mod 2B
     if want_colmean:
-        _, lse0 = ops.attention(qk0, qk1, v1, B, HEADS, T, T, scale, l0, l1, want_lse=True, out=ctx[:half])
-        _, lse1 = ops.attention(qk1, qk0, v0, B, HEADS, T, T, scale, l1, l0, want_lse=True, out=ctx[half:])
-        # attn01 column means -> per set-1 token ; attn10 column means -> per set-0 token
-        col1 = ops.attention_colmean(qk0, qk1, lse0, B, HEADS, T, T, scale, l0, l1)
-        col0 = ops.attention_colmean(qk1, qk0, lse1, B, HEADS, T, T, scale, l1, l0)
-        return _mlp_tail(x, ctx, p), col0, col1
-    ops.attention(qk0, qk1, v1, B, HEADS, T, T, scale, l0, l1, out=ctx[:half])
-    ops.attention(qk1, qk0, v0, B, HEADS, T, T, scale, l1, l0, out=ctx[half:])
+        ctx, lse = ops.attention_cross(qk, v, B, HEADS, T, scale, lens, want_lse=True)
+        col = ops.attention_cross_colmean(qk, lse, B, HEADS, T, scale, lens)
+        # rows 0..B-1: attn10 column means -> per set-0 token ; rows B..2B-1: attn01 column means -> per set-1 token
+        return _mlp_tail(x, ctx, p), col[:B], col[B:]
+    ctx = ops.attention_cross(qk, v, B, HEADS, T, scale, lens)
     return _mlp_tail(x, ctx, p)
 
 

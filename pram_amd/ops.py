@@ -172,6 +172,46 @@ def attention_colmean(q: torch.Tensor, k: torch.Tensor, lse2: torch.Tensor, batc
     return out
 
 
+def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t_max: int, scale: float,
+                    lens: Optional[torch.Tensor] = None, want_lse: bool = False, out: Optional[torch.Tensor] = None,
+                    precision: Optional[str] = None):
+    """Both directions of the matcher's cross attention in one launch.  qk / v: [2*pairs*t_max, >= heads*64] row-major
+    views; sequences 0..pairs-1 are set 0 and attend to set 1 (pairs..2*pairs-1) and vice versa.  lens int32 [2*pairs].
+    Equal, bit for bit, to attention(qk0, qk1, v1) and attention(qk1, qk0, v0) written to the two halves of out."""
+    L = _lib.load()
+    for t, nm in ((qk, "qk"), (v, "v")):
+        _chk(t, nm)
+        assert t.dim() == 2 and t.stride(1) == 1
+    S = 2 * pairs
+    if out is None:
+        out = torch.empty(S * t_max, heads * 64, device=qk.device, dtype=torch.float32)
+    lse = torch.empty(S, heads, t_max, device=qk.device, dtype=torch.float32) if want_lse else None
+    probe = attention_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    prec = precision or attention_precision
+    if prec not in ("f32", "f16"):
+        raise _lib.PramHipError(f"unknown attention precision {prec!r}")
+    fn = L.pram_attention_cross_f32 if prec == "f32" else L.pram_attention_cross_f16_f32
+    _lib.check(fn(_p(qk), qk.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(lse), _p(lens), pairs, heads, t_max,
+                  float(scale), _st()), "pram_attention_cross_" + prec)
+    if probe is not None:
+        e1.record()
+        probe.append((lens, None if lens is None else torch.roll(lens, -pairs), t_max, t_max, heads, S, e0, e1))
+    return (out, lse) if want_lse else out
+
+
+def attention_cross_colmean(qk: torch.Tensor, lse2: torch.Tensor, pairs: int, heads: int, t_max: int, scale: float,
+                            lens=None) -> torch.Tensor:
+    """[2*pairs, t_max]: row kb = per token of sequence kb, mean attention received from the other set's queries."""
+    L = _lib.load()
+    out = torch.zeros(2 * pairs, t_max, device=qk.device, dtype=torch.float32)
+    _lib.check(L.pram_attention_cross_colmean_f32(_p(qk), qk.stride(0), _p(lse2), _p(out), _p(lens), pairs, heads, t_max,
+                                                  float(scale), _st()), "pram_attention_cross_colmean_f32")
+    return out
+
+
 _ws_cache = {}
 
 
@@ -193,7 +233,7 @@ def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, thre
     assert dist.is_contiguous() and dist.dim() == 3
     B, M, ldd = dist.shape
     N = n_valid or ldd
-    ws = _workspace(L.pram_sinkhorn_workspace_bytes(B, M, N), dist.device)
+    ws = _workspace(L.pram_sinkhorn_workspace_bytes(B, M, N), dist.device, "sinkhorn")
     m0 = torch.empty(B, M, device=dist.device, dtype=_INT64)
     m1 = torch.empty(B, N, device=dist.device, dtype=_INT64)
     s0 = torch.empty(B, M, device=dist.device, dtype=torch.float32)
@@ -316,7 +356,7 @@ def select_keypoints(nms: torch.Tensor, conf_th: float, min_keypoints: int, bord
     assert nms.is_contiguous()
     B, H, W = nms.shape
     k = int(max_keypoints)
-    ws = _workspace(L.pram_select_keypoints_workspace_bytes(B, H, W, k), nms.device)
+    ws = _workspace(L.pram_select_keypoints_workspace_bytes(B, H, W, k), nms.device, "select")
     kpts = torch.zeros(B, k, 2, device=nms.device, dtype=torch.float32)
     scores = torch.zeros(B, k, device=nms.device, dtype=torch.float32)
     counts = torch.zeros(B, device=nms.device, dtype=torch.int32)

@@ -7,6 +7,11 @@ device: ragged keypoint counts travel as an int32 ``counts`` array, nothing sync
 host until the caller reads the result record.  Queries shard across GPUs with no data-path
 collective; ``gather_records`` is the single RCCL all-gather of the fixed-size result records
 (SURVEY.md §8(e)).
+
+Recognition and matching both depend only on the extraction, so with few queries in flight (the
+reference's online loop is one frame at a time: 64 attention workgroups for 256 CUs) the matcher
+runs on a second HIP stream next to the recogniser and the two half-empty launch sequences fill
+the chip together; results are identical (same kernels, same launch configurations).
 """
 from __future__ import annotations
 
@@ -18,10 +23,26 @@ from . import ops
 
 
 class QueryPipeline:
-    def __init__(self, sfd2, segnet, matcher, max_keypoints: int = 2048, min_keypoints: int = 128, bg_threshold: float = 0.95):
+    def __init__(self, sfd2, segnet, matcher, max_keypoints: int = 2048, min_keypoints: int = 128, bg_threshold: float = 0.95,
+                 overlap_below: int = 8):
         self.sfd2, self.segnet, self.matcher = sfd2, segnet, matcher
         self.bg_threshold = bg_threshold
         self.cfg = {'min_keypoints': min_keypoints, 'max_keypoints': max_keypoints}
+        self.overlap_below = overlap_below      # batches smaller than this run recognise || match on two streams
+        self._side = None
+
+    def _match(self, ex, ref, W, H):
+        kpts, scores, counts = ex['keypoints'], ex['scores'], ex['counts']
+        data = {
+            'descriptors0': ex['descriptors'], 'keypoints0': kpts, 'scores0': scores, 'lens0': counts,
+            # the reference hands the matcher (1, 3, width, height) (singlemap3d.py:147,152)
+            'image_shape0': (1, 3, W, H),
+            'descriptors1': ref['descriptors'], 'keypoints1': ref['keypoints'], 'scores1': ref['scores'],
+            'image_shape1': (1, 3, W, H),
+        }
+        if 'lens' in ref:
+            data['lens1'] = ref['lens']
+        return self.matcher.produce_matches(data) if hasattr(self.matcher, 'produce_matches') else self.matcher(data)
 
     @torch.no_grad()
     def run(self, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm") -> Dict[str, torch.Tensor]:
@@ -32,6 +53,15 @@ class QueryPipeline:
         ex = self.sfd2.extract_batched(images, self.cfg, per_image_fallback=True)
         kpts, scores, counts = ex['keypoints'], ex['scores'], ex['counts']
         out = {'keypoints': kpts, 'scores': scores, 'counts': counts, 'descriptors': ex['descriptors']}
+        do_match = 'm' in stages and ref is not None
+        forked = do_match and 'r' in stages and B < self.overlap_below
+        if forked:
+            main = torch.cuda.current_stream(images.device)
+            if self._side is None or self._side.device != images.device:
+                self._side = torch.cuda.Stream(device=images.device)
+            self._side.wait_stream(main)                 # extraction results are ready for the side stream
+            with torch.cuda.stream(self._side):
+                m = self._match(ex, ref, W, H)
         if 'r' in stages:
             _, seg = self.sfd2.sample_batched(ex['score_map'], ex['mid_features'], kpts, counts, norm_desc=False)
             pred = self.segnet({'seg_descriptors': seg, 'keypoints': kpts, 'image': images, 'lens': counts})['prediction']
@@ -40,17 +70,13 @@ class QueryPipeline:
             # background mask at the reference's pre_filtering_th (configs/config_train_7scenes_sfd2.yaml:98)
             ids, non_bg, n_non_bg, _ = ops.seg_epilogue(pred, counts, self.bg_threshold)
             out['landmark'], out['non_bg'], out['n_non_bg'] = ids, non_bg, n_non_bg
-        if 'm' in stages and ref is not None:
-            data = {
-                'descriptors0': ex['descriptors'], 'keypoints0': kpts, 'scores0': scores, 'lens0': counts,
-                # the reference hands the matcher (1, 3, width, height) (singlemap3d.py:147,152)
-                'image_shape0': (1, 3, W, H),
-                'descriptors1': ref['descriptors'], 'keypoints1': ref['keypoints'], 'scores1': ref['scores'],
-                'image_shape1': (1, 3, W, H),
-            }
-            if 'lens' in ref:
-                data['lens1'] = ref['lens']
-            m = self.matcher.produce_matches(data) if hasattr(self.matcher, 'produce_matches') else self.matcher(data)
+        if do_match:
+            if forked:
+                main.wait_stream(self._side)
+                for t in (m['matches0'], m['matching_scores0']):
+                    t.record_stream(main)               # allocated on the side stream, consumed on the caller's
+            else:
+                m = self._match(ex, ref, W, H)
             out['matches0'] = m['matches0']
             out['matching_scores0'] = m['matching_scores0']
         return out

@@ -205,6 +205,35 @@ def test_attention_ragged_equals_unpadded(dev):
         assert torch.equal(out[b, :n], solo)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_attention_cross_equals_two_calls(dev, prec):
+    """the single-launch cross attention (both directions, ragged lens) == two separate launches, bit for bit,
+    outputs, log-sum-exp and the AdaGML column means alike"""
+    from pram_amd import ops
+    Hh, T, B = 4, 300, 3
+    qk, v = rnd(7, "cx/qk", (2 * B * T, 256)).to(dev), rnd(7, "cx/v", (2 * B * T, 256)).to(dev)
+    lens = torch.tensor([300, 211, 64, 97, 300, 130], dtype=torch.int32, device=dev)
+    half = B * T
+    o, lse = ops.attention_cross(qk, v, B, Hh, T, 0.125, lens, want_lse=True, precision=prec)
+    o0, l0 = ops.attention(qk[:half], qk[half:], v[half:], B, Hh, T, T, 0.125, lens[:B], lens[B:], want_lse=True, precision=prec)
+    o1, l1 = ops.attention(qk[half:], qk[:half], v[:half], B, Hh, T, T, 0.125, lens[B:], lens[:B], want_lse=True, precision=prec)
+    for s in range(2 * B):
+        n = int(lens[s])
+        want_o, want_l = (o0, l0) if s < B else (o1, l1)
+        i = s % B
+        assert torch.equal(o.view(2 * B, T, 256)[s, :n], want_o.view(B, T, 256)[i, :n])
+        assert torch.equal(lse[s, :, :n], want_l[i, :, :n])
+    if prec == "f32":
+        col = ops.attention_cross_colmean(qk, lse, B, Hh, T, 0.125, lens)
+        c1 = ops.attention_colmean(qk[:half], qk[half:], l0, B, Hh, T, T, 0.125, lens[:B], lens[B:])   # per set-1 token
+        c0 = ops.attention_colmean(qk[half:], qk[:half], l1, B, Hh, T, T, 0.125, lens[B:], lens[:B])   # per set-0 token
+        assert torch.equal(col[:B], c0) and torch.equal(col[B:], c1)
+    # no lens
+    o2 = ops.attention_cross(qk, v, B, Hh, T, 0.125, precision=prec)
+    o20 = ops.attention(qk[:half], qk[half:], v[half:], B, Hh, T, T, 0.125, precision=prec)
+    assert torch.equal(o2[:half], o20)
+
+
 # ------------------------------------------------------------------ sinkhorn / matches
 def _sink_input(tag, m, n):
     M = W.normal(11, f"sink/{tag}", (2, m, n), 2.0)
