@@ -609,3 +609,47 @@ def extract_sfd2_return(sd: SD, img: torch.Tensor, conf_th=0.001, topK=-1, scale
         idx = np.argsort(-np.array(scs, dtype=float), kind="stable")[:topK]
         kp, scs, descs = kp[idx], scs[idx], descs[idx]
     return {"keypoints": np.array(kp, dtype=float), "descriptors": np.array(descs, dtype=float), "scores": np.array(scs, dtype=float)}
+
+
+# ------------------------------------------------------------------ edge formats
+# Parity status of this block: the reference modules that hold these lines import h5py, which is not installed, so
+# they cannot be executed here — the conversions are restated from the cited lines (UNPINNED by execution; the
+# arithmetic is three casts and one affine map).
+def names_to_pair(name0: str, name1: str, separator: str = "/") -> str:
+    """colmap_utils/parsers.py:79-80"""
+    return separator.join((name0.replace("/", "-"), name1.replace("/", "-")))
+
+
+def writer_encode(pred: dict) -> dict:
+    """localization/match_features_batch.py:119-129 (writer_fn): batch element 0, indices -> int16, scores -> fp16"""
+    out = {"matches0": pred["matches0"][0].cpu().short().numpy()}
+    if "matching_scores0" in pred:
+        out["matching_scores0"] = pred["matching_scores0"][0].cpu().half().numpy()
+    return out
+
+
+def feature_encode(pred: dict, image_shape, original_size) -> dict:
+    """localization/extract_features.py:215-232: descriptors transposed to [D, N]; keypoints mapped to the original
+    image; image_size = original (w, h).  image_shape = data['image'].shape (.., h, w)."""
+    import numpy as np
+    out = dict(pred)
+    out["descriptors"] = pred["descriptors"].transpose()
+    out["image_size"] = original_size = np.asarray(original_size)
+    if "keypoints" in pred:
+        size = np.array(tuple(image_shape)[-2:][::-1])
+        scales = (original_size / size).astype(np.float32)
+        out["keypoints"] = (pred["keypoints"] + .5) * scales[None] - .5
+    return out
+
+
+def pair_item(grp0: dict, grp1: dict) -> dict:
+    """localization/match_features_batch.py:95-113 (FeaturePairsDataset.__getitem__) on two feature groups given as
+    {name: ndarray}"""
+    data = {}
+    for grp, sfx in ((grp0, "0"), (grp1, "1")):
+        for k, v in grp.items():
+            data[k + sfx] = torch.from_numpy(v.__array__()).float()
+            if k == "descriptors":
+                data[k + sfx] = data[k + sfx].t()
+        data["image" + sfx] = torch.empty((1,) + tuple(grp["image_size"])[::-1])
+    return data

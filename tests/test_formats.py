@@ -1,0 +1,108 @@
+"""Edge formats and the batch pair-matching driver (a17)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from pram_amd.localization import formats as F
+
+
+def test_pair_names_and_retrieval(tmp_path):
+    assert F.names_to_pair("seq1/frame-0.png", "db/a/b.jpg") == "seq1-frame-0.png/db-a-b.jpg" == R.names_to_pair("seq1/frame-0.png", "db/a/b.jpg")
+    assert F.names_to_pair_old("a/b", "c") == "a-b_c"
+    p = tmp_path / "pairs.txt"
+    p.write_text("q1 r1\nq1 r2\nq2 r1\n")
+    assert F.parse_retrieval(p) == {"q1": ["r1", "r2"], "q2": ["r1"]}
+
+
+def test_find_unique_new_pairs():
+    pairs = [("a", "b"), ("b", "a"), ("a", "c"), ("a", "b"), ("c", "d")]
+    assert F.find_unique_new_pairs(pairs) == [("a", "b"), ("a", "c"), ("c", "d")]
+    st = F.DictStore()
+    F.write_matches(st, F.names_to_pair("c", "a"), {"matches0": np.zeros(3, np.int16)})      # reverse order, new naming
+    st.create_group(F.names_to_pair_old("c", "d"))                                             # old naming
+    assert F.find_unique_new_pairs(pairs, st) == [("a", "b")]
+
+
+def test_match_encoding_matches_reference_casts():
+    m = torch.tensor([[5, -1, 32767, 40000, 0]], dtype=torch.int64)          # 40000 wraps in int16, as .short() does
+    s = torch.tensor([[0.2, 0.0, 0.33333334, 0.99951172, 1e-8]], dtype=torch.float32)
+    enc = F.encode_matches(m[0], s[0])
+    want = R.writer_encode({"matches0": m, "matching_scores0": s})
+    assert enc["matches0"].dtype == np.int16 and enc["matching_scores0"].dtype == np.float16
+    assert np.array_equal(enc["matches0"], want["matches0"]) and np.array_equal(enc["matches0"], np.array([5, -1, 32767, -25536, 0], np.int16))
+    assert np.array_equal(enc["matching_scores0"].view(np.uint16), want["matching_scores0"].view(np.uint16))
+    st = F.DictStore()
+    F.write_matches(st, "q/r", enc)
+    F.write_matches(st, "q/r", enc)            # an existing group is replaced, not an error
+    m2, s2 = F.read_matches(st, "q", "r")
+    assert np.array_equal(m2, enc["matches0"]) and np.array_equal(s2, enc["matching_scores0"])
+    assert "matching_scores0" not in F.encode_matches(m[0])
+
+
+def test_feature_encoding_and_pair_item_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    n = 37
+    pred = {"keypoints": rng.integers(4, 600, (n, 2)).astype(np.float64), "scores": rng.random(n),
+            "descriptors": rng.standard_normal((n, 128))}
+    image_hw, orig_wh = (480, 640), np.array([1296, 968])
+    enc = F.encode_features(pred, image_hw, orig_wh)
+    want = R.feature_encode(pred, (1, 3) + image_hw, orig_wh)
+    assert enc["descriptors"].shape == (128, n)
+    for k in want:
+        assert np.array_equal(enc[k], want[k]), k
+    # the affine map by hand: x' = (x + .5) * float32(1296 / 640) - .5
+    sx = np.float32(1296 / 640)
+    assert np.array_equal(enc["keypoints"][:, 0], (pred["keypoints"][:, 0] + .5) * sx - .5)
+    st = F.DictStore()
+    F.write_features(st, "seq/a.png", enc)
+    F.write_features(st, "seq/b.png", enc)
+    st.save(tmp_path / "feats.npz")
+    st2 = F.DictStore.load(tmp_path / "feats.npz")
+    item = F.read_feature_pair(st2, "seq/a.png", st2, "seq/b.png")
+    want_item = R.pair_item(dict(st["seq/a.png"].items()), dict(st["seq/b.png"].items()))
+    assert set(item) == set(want_item)
+    for k in item:
+        if k.startswith("image") and not k.startswith("image_size"):
+            assert tuple(item[k].shape) == tuple(want_item[k].shape) == (1, 968, 1296)
+        else:
+            assert torch.equal(item[k], want_item[k]), k
+    assert item["descriptors0"].shape == (n, 128) and item["descriptors0"].dtype == torch.float32
+
+
+def test_open_store_without_h5py_says_so():
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py is installed here")
+    except ImportError:
+        with pytest.raises(ImportError, match="DictStore"):
+            F.open_store("/tmp/x.h5")
+
+
+@pytest.mark.gpu
+def test_match_pairs_batched_equals_reference_loop():
+    """match_pairs (padded batches, device-side int16 / fp16 casts) == the reference's loop: one pair at a time through
+    the plugin, writer_fn's casts (match_features_batch.py:214-228,119-129)."""
+    from pram_amd import weights as Wt
+    from pram_amd.nets.gml import GML
+    dev = torch.device("cuda:0")
+    net = GML({}).eval()
+    net.load_state_dict(Wt.make_state_dict("gml", net.state_dict(), seed=7), strict=True)
+    net = net.to(dev)
+    feats = F.DictStore()
+    names, sizes = [f"seq/f{i}.png" for i in range(5)], [300, 211, 256, 97, 180]
+    for i, (nm, n) in enumerate(zip(names, sizes)):
+        sp = Wt.synthetic_match_pair(40 + i, n, n)
+        pred = {"keypoints": sp["keypoints0"].double().numpy(), "scores": sp["scores0"].double().numpy(),
+                "descriptors": sp["descriptors0"].double().numpy()}
+        F.write_features(feats, nm, F.encode_features(pred, (480, 640), np.array([640, 480])))
+    pairs = [(names[0], names[1]), (names[2], names[3]), (names[4], names[0]), (names[1], names[2])]
+    out = F.DictStore()
+    assert F.match_pairs(net, pairs, feats, feats, out, batch_size=3, device=dev) == 4
+    for a, b in pairs:
+        item = F.read_feature_pair(feats, a, feats, b)
+        data = {k: (v[None].to(dev) if not k.startswith("image") else v[None]) for k, v in item.items()}
+        pred = net.produce_matches(data)
+        want = R.writer_encode({k: v.cpu() for k, v in pred.items()})
+        m, s = F.read_matches(out, a, b)
+        assert np.array_equal(m, want["matches0"]) and np.array_equal(s.view(np.uint16), want["matching_scores0"].view(np.uint16))
