@@ -89,7 +89,14 @@ int pram_fourier_encoding_f32(const float* kpts, const float* wr, float cx, floa
  * log2-domain log-sum-exp [batch][heads][m_max] for pram_attention_colmean_f32. */
 int pram_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                        float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens,
-                       int batch, int heads, int m_max, int n_max, float scale, void* stream);
+                       int batch, int heads, int m_max, int n_max, float scale, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Keys are reduced in chunks of 512 folded in order.  A launch with fewer than 512 (batch, head, 128-row) units
+ * — one to four query frames — cannot fill the chip, so when the caller passes a workspace of at least this many
+ * bytes the chunks run as separate workgroups and a second kernel applies the same fold; the result is bit-identical
+ * with or without the workspace.  Returns 0 when the launch would not be split (pass NULL / 0 then). */
+size_t pram_attention_workspace_bytes(int batch, int heads, int m_max, int n_max);
 
 /* The "fp16 MFMA path" of BASELINE config C5: same contract as pram_attention_f32 (fp32 tensors in HBM),
  * but Q/K/V and the probabilities are rounded to fp16 and multiplied on v_mfma_f32_32x32x16_f16 (fp32
@@ -104,7 +111,8 @@ int pram_attention_f16_f32(const float* q, int ldq, const float* k, int ldk, con
  * (s + pairs) mod 2*pairs of qk / v.  lens [2*pairs] (optional).  Per sequence the arithmetic is exactly
  * pram_attention_f32's (same kernel, same tiling), so the result equals two separate calls bit for bit. */
 int pram_attention_cross_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
-                             const int* lens, int pairs, int heads, int t_max, float scale, void* stream);
+                             const int* lens, int pairs, int heads, int t_max, float scale, void* workspace,
+                             size_t workspace_bytes /* pram_attention_workspace_bytes(2*pairs, heads, t_max, t_max) */, void* stream);
 int pram_attention_cross_f16_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
                                  const int* lens, int pairs, int heads, int t_max, float scale, void* stream);
 /* Column means for the same pairing: colmean [2*pairs][t_max]; row kb holds, per token of sequence kb, the mean

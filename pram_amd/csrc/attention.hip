@@ -20,6 +20,14 @@
 // __shfl_xor(…, 32) for the row max.  At the f32 MFMA rate (64 cycles per instruction) the
 // kernel is matrix-pipe bound: 128 MFMA = 8192 cycles per 64-key tile per wave against ~64
 // v_exp + ~200 VALU and 80 LDS reads.
+//
+// Key chunks.  The keys of a sequence are processed in chunks of CHUNK_TILES tiles (512 keys): every chunk runs the
+// online softmax from a fresh state, is normalised, and is folded into the running result with fold_chunk() — a
+// fixed left fold in chunk order.  One workgroup normally walks all chunks of its 128 query rows ("fused").  When a
+// launch has too few (batch, head, q-tile) units to fill 2 x 256 workgroup slots — one or two query frames — the
+// chunks become a grid dimension instead ("split"): each workgroup writes its normalised chunk result to a
+// workspace and combine_kernel applies the SAME fold in the SAME order, so the output does not depend on which
+// mode ran, bit for bit.  That is what lets a padded batch element still equal its B = 1 run exactly.
 #include "common.h"
 #include <math.h>
 
@@ -30,7 +38,23 @@ constexpr int QW = 32;    // query rows per wave
 constexpr int NW = 4;     // waves per workgroup
 constexpr int BQ = QW * NW;
 constexpr int BKV = 64;   // keys per LDS tile
+constexpr int CHUNK_TILES = 8;                  // tiles per key chunk
+constexpr int CHUNK = CHUNK_TILES * BKV;        // 512 keys
+constexpr int SPLIT_BELOW = 2 * 256;            // fused launches with fewer workgroups than this are split
 constexpr float LOG2E = 1.4426950408889634f;
+
+// Fold one normalised chunk result (oc, lc = log2-sum-exp of its scores) into the running (ot, lt).  Used by the
+// attention kernel (fused mode) and by combine_kernel (split mode): identical operations in identical order.
+// Starting from lt = -inf, ot = 0 the first fold returns (oc, lc) exactly.
+__device__ __forceinline__ void fold_weights(float lt, float lc, float* at, float* ac, float* lnew) {
+    const float mx = fmaxf(lt, lc);
+    const float wt = exp2f(lt - mx), wc = exp2f(lc - mx);
+    const float den = wt + wc;
+    *at = wt / den;
+    *ac = wc / den;
+    *lnew = mx + log2f(den);
+}
+__device__ __forceinline__ float fold_value(float ot, float oc, float at, float ac) { return ot * at + oc * ac; }
 
 struct AttnArgs {
     const float* q; const float* k; const float* v;
@@ -41,6 +65,9 @@ struct AttnArgs {
     float scale2;
     int q_tiles;
     int kv_shift;   // keys / values of batch element b come from element (b + kv_shift) % batch (cross attention: both directions in one launch)
+    int nsplit;     // 1: fused (a workgroup folds all key chunks); > 1: blockIdx.y = key chunk, results go to part_o / part_l
+    float* part_o;  // [nsplit][batch * m_max][heads * D]   normalised chunk outputs
+    float* part_l;  // [nsplit][batch][heads][m_max]        their log2-sum-exp
 };
 
 struct Smem {
@@ -103,17 +130,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         }
     };
 
-    const int nkt = (klen + BKV - 1) / BKV;
-    gload(0);
-    lstore(0);
+    const int nkt_all = (klen + BKV - 1) / BKV;
+    const int split = p.nsplit > 1 ? (int)blockIdx.y : 0;
+    const int kt0 = split * CHUNK_TILES;                                   // first tile of this workgroup
+    const int nkt = p.nsplit > 1 ? min(nkt_all, kt0 + CHUNK_TILES) : nkt_all;   // one past its last tile
+    if (kt0 >= nkt) return;                                                // this chunk lies beyond klen
+    gload(kt0);
+    lstore(kt0 & 1);
     __syncthreads();
 
     float m_run = -1.0e30f, l_run = 0.f;
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+    float o_tot[2][16], l_tot2 = -INFINITY;      // running fold over finished chunks
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o_tot[0][e] = 0.f; o_tot[1][e] = 0.f; }
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
         if (more) gload(kt + 1);
@@ -153,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 kmma(c + 1, kB0, kB1);
             }
-            // ---- mask keys beyond klen (last tile only)
-            if (!more && (klen & (BKV - 1))) {
+            // ---- mask keys beyond klen (last tile of the sequence only)
+            if (kt + 1 == nkt_all && (klen & (BKV - 1))) {
                 const int kbase = kt * BKV;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -218,26 +252,80 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 vmma(t, 12, vB);
             }
+            // ---- end of a key chunk: normalise it, fold it into the running result, start afresh
+            if (((kt + 1) % CHUNK_TILES) == 0 || !more) {
+                const float l_c = l_run + __shfl_xor(l_run, 32, 64);
+                const float inv = 1.0f / l_c;
+                const float lse_c = m_run + log2f(l_c);
+                if (p.nsplit > 1) {          // split mode: the chunk result itself is the output of this workgroup
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { o_tot[0][e] = oacc[0][e] * inv; o_tot[1][e] = oacc[1][e] * inv; }
+                    l_tot2 = lse_c;
+                } else {
+                    float at, ac, lnew;
+                    fold_weights(l_tot2, lse_c, &at, &ac, &lnew);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        o_tot[0][e] = fold_value(o_tot[0][e], oacc[0][e] * inv, at, ac);
+                        o_tot[1][e] = fold_value(o_tot[1][e], oacc[1][e] * inv, at, ac);
+                    }
+                    l_tot2 = lnew;
+                }
+                m_run = -1.0e30f;
+                l_run = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+            }
         }
         if (more) lstore(cur ^ 1);
         __syncthreads();
     }
 
-    if (!wave_active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_ok) {
-        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+    if (!wave_active || !q_ok) return;
+    const size_t row = (size_t)b * p.m_max + qrow;
+    float* op = p.nsplit > 1 ? p.part_o + ((size_t)split * p.batch * p.m_max + row) * (p.heads * D) + head * D
+                             : p.out + row * p.ldo + head * D;
 #pragma unroll
-        for (int dn = 0; dn < 2; ++dn)
+    for (int dn = 0; dn < 2; ++dn)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
-                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
-                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
-            }
-        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + log2f(l_tot);
+        for (int g = 0; g < 4; ++g) {
+            const float4 o = make_float4(o_tot[dn][4 * g + 0], o_tot[dn][4 * g + 1], o_tot[dn][4 * g + 2], o_tot[dn][4 * g + 3]);
+            *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
+        }
+    if (h == 0) {
+        const size_t li = ((size_t)b * p.heads + head) * p.m_max + qrow;
+        if (p.nsplit > 1) p.part_l[(size_t)split * p.batch * p.heads * p.m_max + li] = l_tot2;
+        else if (p.lse2) p.lse2[li] = l_tot2;
     }
+}
+
+// Split mode, second step: one wave per (query row, head), one lane per output dim; the left fold over the key
+// chunks of that row in chunk order — fold_weights / fold_value exactly as the fused kernel applies them.
+__global__ __launch_bounds__(256) void combine_kernel(AttnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, qrow, head)
+    const long long units = (long long)p.batch * p.m_max * p.heads;
+    if (unit >= units) return;
+    const int head = (int)(unit % p.heads);
+    const long long row = unit / p.heads;                                       // b * m_max + qrow
+    const int b = (int)(row / p.m_max), qrow = (int)(row - (long long)b * p.m_max);
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
+    if (qrow >= qlen || klen <= 0) return;
+    const int nchunk = (klen + CHUNK - 1) / CHUNK;
+    const size_t li = ((size_t)b * p.heads + head) * p.m_max + qrow;
+    float ot = 0.f, lt = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        const float oc = p.part_o[((size_t)c * p.batch * p.m_max + row) * (p.heads * D) + head * D + lane];
+        const float lc = p.part_l[(size_t)c * p.batch * p.heads * p.m_max + li];
+        float at, ac, lnew;
+        fold_weights(lt, lc, &at, &ac, &lnew);
+        ot = fold_value(ot, oc, at, ac);
+        lt = lnew;
+    }
+    p.out[(size_t)row * p.ldo + head * D + lane] = ot;
+    if (p.lse2 && lane == 0) p.lse2[li] = lt;
 }
 
 // ---------------------------------------------------------------- column means (AdaGML)
@@ -324,29 +412,60 @@ __global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
 
 }  // namespace
 
+// fused or split launch (see "Key chunks" above).  The mode never changes the result.
+static size_t split_bytes(int batch, int heads, int m_max, int n_max) {
+    const long units = (long)batch * heads * cdiv(m_max, BQ);
+    const int nsplit = cdiv(n_max, CHUNK);
+    if (units >= SPLIT_BELOW || nsplit < 2) return 0;
+    return (size_t)nsplit * batch * m_max * (heads * D + heads) * sizeof(float);
+}
+
+static void launch_attention(AttnArgs& p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const size_t need = split_bytes(p.batch, p.heads, p.m_max, p.n_max);
+    const int units = p.batch * p.heads * p.q_tiles;
+    if (need == 0 || workspace == nullptr || workspace_bytes < need) {
+        p.nsplit = 1;
+        p.part_o = p.part_l = nullptr;
+        hipLaunchKernelGGL(attention_kernel, dim3(units), dim3(256), 0, st, p);
+        return;
+    }
+    p.nsplit = cdiv(p.n_max, CHUNK);
+    p.part_o = (float*)workspace;
+    p.part_l = p.part_o + (size_t)p.nsplit * p.batch * p.m_max * p.heads * D;
+    hipLaunchKernelGGL(attention_kernel, dim3(units, p.nsplit), dim3(256), 0, st, p);
+    const long long rows = (long long)p.batch * p.m_max * p.heads;
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+}
+
+extern "C" size_t pram_attention_workspace_bytes(int batch, int heads, int m_max, int n_max) {
+    return split_bytes(batch, heads, m_max, n_max);
+}
+
 extern "C" int pram_attention_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                   float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens, int batch,
-                                  int heads, int m_max, int n_max, float scale, void* stream) {
+                                  int heads, int m_max, int n_max, float scale, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
     PRAM_REQUIRE(q && k && v && out, "pram_attention_f32: null pointer");
     PRAM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "pram_attention_f32: ld must be a multiple of 4");
     PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0, "pram_attention_f32: bad sizes");
     if (batch == 0 || m_max == 0) return PRAM_OK;
     PRAM_REQUIRE(n_max > 0, "pram_attention_f32: empty key set");
     AttnArgs p{q, k, v, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max, scale * LOG2E,
-               cdiv(m_max, BQ), 0};
-    hipLaunchKernelGGL(attention_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+               cdiv(m_max, BQ), 0, 1, nullptr, nullptr};
+    launch_attention(p, workspace, workspace_bytes, (hipStream_t)stream);
     return pram_launch_status("pram_attention_f32");
 }
 
 extern "C" int pram_attention_cross_f32(const float* qk, int ldqk, const float* v, int ldv, float* out, int ldo, float* lse2,
-                                        const int* lens, int pairs, int heads, int t_max, float scale, void* stream) {
+                                        const int* lens, int pairs, int heads, int t_max, float scale, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
     PRAM_REQUIRE(qk && v && out, "pram_attention_cross_f32: null pointer");
     PRAM_REQUIRE(ldqk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "pram_attention_cross_f32: ld must be a multiple of 4");
     PRAM_REQUIRE(pairs >= 0 && heads > 0 && t_max >= 0, "pram_attention_cross_f32: bad sizes");
     if (pairs == 0 || t_max == 0) return PRAM_OK;
     AttnArgs p{qk, qk, v, out, lse2, lens, lens, ldqk, ldqk, ldv, ldo, 2 * pairs, heads, t_max, t_max, scale * LOG2E,
-               cdiv(t_max, BQ), pairs};
-    hipLaunchKernelGGL(attention_kernel, dim3(2 * pairs * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+               cdiv(t_max, BQ), pairs, 1, nullptr, nullptr};
+    launch_attention(p, workspace, workspace_bytes, (hipStream_t)stream);
     return pram_launch_status("pram_attention_cross_f32");
 }
 

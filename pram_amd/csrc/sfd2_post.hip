@@ -111,13 +111,22 @@ constexpr int SEL_KMAX = 8192;    // max_keypoints supported by the in-LDS sort
 struct SelWs {
     int* cnt_hi;            // [batch]   #(nms >= conf_th), no border test  (fallback decision)
     unsigned* cand;         // [batch][h*w]  flat indices of candidates, row-major order
+    unsigned* cbits;        // [batch][h*w]  their score bit patterns (same order), so later passes stream one array
 };
 
 __global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict__ nms, int hw, float th, int* __restrict__ cnt) {
     const int b = blockIdx.y;
     const float* img = nms + (size_t)b * hw;
     int c = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) c += img[i] >= th;
+    if ((hw & 3) == 0) {
+        const float4* img4 = reinterpret_cast<const float4*>(img);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (hw >> 2); i += gridDim.x * 256) {
+            const float4 v = img4[i];
+            c += (v.x >= th) + (v.y >= th) + (v.z >= th) + (v.w >= th);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) c += img[i] >= th;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[b], c);
@@ -161,22 +170,50 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
     const int hw = h * w;
     const float* img = nms + (size_t)b * hw;
     unsigned* cand = ws.cand + (size_t)b * hw;
+    unsigned* cbits = ws.cbits + (size_t)b * hw;
     const int ref = fallback_ref < 0 ? b : fallback_ref;
     const float th = (ws.cnt_hi[ref] <= min_kp) ? conf_th * 0.5f : conf_th;
 
-    // ---- pass 1: ordered compaction of the candidates (>= th, inside the border)
+    // ---- pass 1: ordered compaction of the candidates (>= th, inside the border).  A thread owns 8 consecutive
+    // pixels per sweep (two float4 loads; the next sweep's loads are in flight during the block scan), so one image
+    // is 38 scans instead of 300 — the kernel is a single workgroup and every scan costs a load latency + 3 barriers.
+    constexpr int PER = 8;
+    auto load8 = [&](int base, float (&v)[PER]) {
+        const int i0 = base + tid * PER;
+        if (i0 + PER <= hw && (hw & 3) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(img + i0), bb = *reinterpret_cast<const float4*>(img + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) v[j] = (i0 + j < hw) ? img[i0 + j] : -1.f;
+        }
+    };
     int c = 0;
-    for (int base = 0; base < hw; base += SEL_T) {
-        const int i = base + tid;
-        bool keep = false;
-        if (i < hw) {
-            const int y = i / w, x = i - y * w;
-            keep = img[i] >= th && y >= border && y < h - border && x >= border && x < w - border;
+    float cur[PER], nxt[PER];
+    load8(0, cur);
+    for (int base = 0; base < hw; base += SEL_T * PER) {
+        if (base + SEL_T * PER < hw) load8(base + SEL_T * PER, nxt);
+        const int i0 = base + tid * PER;
+        int y = i0 / w, x = i0 - y * w;
+        unsigned keepmask = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool keep = (i0 + j < hw) && cur[j] >= th && y >= border && y < h - border && x >= border && x < w - border;
+            keepmask |= (keep ? 1u : 0u) << j;
+            if (++x == w) { x = 0; ++y; }
         }
         int tot;
-        const int pos = block_excl_scan(keep ? 1 : 0, sbuf, &tot);
-        if (keep) cand[c + pos] = (unsigned)i;
+        int pos = c + block_excl_scan(__popc(keepmask), sbuf, &tot);
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (keepmask & (1u << j)) {
+                cand[pos] = (unsigned)(i0 + j);
+                cbits[pos] = __float_as_uint(cur[j]);
+                ++pos;
+            }
         c += tot;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) cur[j] = nxt[j];
     }
     __threadfence_block();
     __syncthreads();
@@ -188,7 +225,7 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
             const unsigned idx = cand[i];
             ko[2 * i] = (float)(idx % w);
             ko[2 * i + 1] = (float)(idx / w);
-            so[i] = img[idx];
+            so[i] = __uint_as_float(cbits[i]);
         }
         if (tid == 0) counts[b] = c;
         return;
@@ -202,9 +239,13 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = tid; i < c; i += SEL_T) {
-            const unsigned bits = __float_as_uint(img[cand[i]]);
-            if ((bits & himask) == prefix) atomicAdd(&hist[(bits >> shift) & 255], 1);
+        for (int i0 = tid; i0 < c; i0 += 4 * SEL_T) {      // four independent loads in flight per thread
+            unsigned bits[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bits[u] = (i0 + u * SEL_T < c) ? cbits[i0 + u * SEL_T] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * SEL_T < c && (bits[u] & himask) == prefix) atomicAdd(&hist[(bits[u] >> shift) & 255], 1);
         }
         __syncthreads();
         if (tid == 0) {
@@ -230,7 +271,7 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
         bool gt = false, eq = false;
         if (i < c) {
             idx = cand[i];
-            bits = __float_as_uint(img[idx]);
+            bits = cbits[i];
             gt = bits > tbits;
             eq = bits == tbits;
         }
@@ -409,6 +450,8 @@ static SelWs sel_carve(void* ws, int batch, int h, int w, size_t* total) {
     s.cnt_hi = (int*)(base + off);
     off += ((size_t)batch * 4 + 255) & ~(size_t)255;
     s.cand = (unsigned*)(base + off);
+    off += ((size_t)batch * h * w * 4 + 255) & ~(size_t)255;
+    s.cbits = (unsigned*)(base + off);
     off += ((size_t)batch * h * w * 4 + 255) & ~(size_t)255;
     if (total) *total = off;
     return s;

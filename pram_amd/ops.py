@@ -132,6 +132,17 @@ def _w16(w: torch.Tensor) -> torch.Tensor:
     return h
 
 
+attention_split = True      # False: never hand the kernel a split workspace (tests compare both modes bit for bit)
+
+
+def _attention_ws(L, batch, heads, m_max, n_max, device):
+    """workspace for the split (small-launch) mode, per stream: two streams may run attention concurrently"""
+    nb = int(L.pram_attention_workspace_bytes(batch, heads, m_max, n_max)) if attention_split else 0
+    if nb == 0:
+        return None, 0
+    return _workspace(nb, device, f"attention/{_st()}"), nb
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int,
               scale: float, q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None,
               want_lse: bool = False, out: Optional[torch.Tensor] = None, precision: Optional[str] = None):
@@ -150,10 +161,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     prec = precision or attention_precision
     if prec not in ("f32", "f16"):
         raise _lib.PramHipError(f"unknown attention precision {prec!r}")
-    fn = L.pram_attention_f32 if prec == "f32" else L.pram_attention_f16_f32
-    _lib.check(fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
-                  _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
-               "pram_attention_" + prec)
+    if prec == "f32":
+        ws, nb = _attention_ws(L, batch, heads, m_max, n_max, q.device)
+        rc = L.pram_attention_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                  _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _p(ws), nb, _st())
+    else:
+        rc = L.pram_attention_f16_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                      _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), _st())
+    _lib.check(rc, "pram_attention_" + prec)
     if probe is not None:
         e1.record()
         # algorithmic FLOPs of QK^T + PV: 4 * m_b * n_b * 64 per (batch element, head), from the ACTUAL ragged
@@ -193,9 +208,14 @@ def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t
     prec = precision or attention_precision
     if prec not in ("f32", "f16"):
         raise _lib.PramHipError(f"unknown attention precision {prec!r}")
-    fn = L.pram_attention_cross_f32 if prec == "f32" else L.pram_attention_cross_f16_f32
-    _lib.check(fn(_p(qk), qk.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(lse), _p(lens), pairs, heads, t_max,
-                  float(scale), _st()), "pram_attention_cross_" + prec)
+    if prec == "f32":
+        ws, nb = _attention_ws(L, S, heads, t_max, t_max, qk.device)
+        rc = L.pram_attention_cross_f32(_p(qk), qk.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(lse), _p(lens),
+                                        pairs, heads, t_max, float(scale), _p(ws), nb, _st())
+    else:
+        rc = L.pram_attention_cross_f16_f32(_p(qk), qk.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(lse), _p(lens),
+                                            pairs, heads, t_max, float(scale), _st())
+    _lib.check(rc, "pram_attention_cross_" + prec)
     if probe is not None:
         e1.record()
         probe.append((lens, None if lens is None else torch.roll(lens, -pairs), t_max, t_max, heads, S, e0, e1))

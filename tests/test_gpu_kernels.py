@@ -205,6 +205,35 @@ def test_attention_ragged_equals_unpadded(dev):
         assert torch.equal(out[b, :n], solo)
 
 
+@pytest.mark.parametrize("S,T,lens", [(1, 2048, None), (2, 1500, [1500, 700]), (3, 1100, [1100, 513, 40]), (1, 600, [512])])
+def test_attention_split_equals_fused(dev, S, T, lens):
+    """Small launches run the key chunks as separate workgroups + a combine pass; the fold is the one the fused kernel
+    applies, in the same order: outputs and log-sum-exp are identical bit for bit (so a batch element still equals
+    its B = 1 run whichever mode either launch used)."""
+    from pram_amd import ops
+    Hh = 4
+    q, k, v = rnd(8, "sf/q", (S * T, 256)).to(dev), rnd(8, "sf/k", (S * T, 256)).to(dev), rnd(8, "sf/v", (S * T, 256)).to(dev)
+    L = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    assert ops._lib.load().pram_attention_workspace_bytes(S, Hh, T, T) > 0
+    try:
+        ops.attention_split = True
+        o1, l1 = ops.attention(q, k, v, S, Hh, T, T, 0.125, L, L, want_lse=True)
+        ops.attention_split = False
+        o0, l0 = ops.attention(q, k, v, S, Hh, T, T, 0.125, L, L, want_lse=True)
+    finally:
+        ops.attention_split = True
+    for b in range(S):
+        n = lens[b] if lens else T
+        assert torch.equal(o1.view(S, T, 256)[b, :n], o0.view(S, T, 256)[b, :n])
+        assert torch.equal(l1[b, :, :n], l0[b, :, :n])
+    # and against fp64
+    b, n = 0, (lens[0] if lens else T)
+    f = lambda t: t.view(S, T, 4, 64)[b, :n].permute(1, 0, 2).double().cpu()[None]
+    ref, _ = _attn_ref(f(q), f(k), f(v), 0.125)
+    got = o1.view(S, T, 4, 64)[b, :n].permute(1, 0, 2).cpu()[None]
+    assert H.maxdiff(got, ref) < 2e-5
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16"])
 def test_attention_cross_equals_two_calls(dev, prec):
     """the single-launch cross attention (both directions, ragged lens) == two separate launches, bit for bit,
