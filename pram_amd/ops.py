@@ -140,7 +140,7 @@ def _attention_ws(L, batch, heads, m_max, n_max, device):
     nb = int(L.pram_attention_workspace_bytes(batch, heads, m_max, n_max)) if attention_split else 0
     if nb == 0:
         return None, 0
-    return _workspace(nb, device, f"attention/{_st()}"), nb
+    return _workspace(nb, device, "attention"), nb
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int,
@@ -236,7 +236,9 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
-    key = (str(device), tag)
+    """Scratch memory owned by (device, purpose, stream): launches on different streams never share a workspace, so
+    several batches can be in flight at once."""
+    key = (str(device), tag, _st())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)

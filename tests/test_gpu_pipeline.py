@@ -68,3 +68,29 @@ def test_pipeline_matches_per_query_oracle(dev):
         assert torch.equal(out["matches0"][b, :n].cpu(), m["matches0"][0])
         assert H.maxdiff(out["matching_scores0"][b, :n], m["matching_scores0"][0]) < 1e-3
     assert bool((rec[1, counts[1]:, 4] == -1).all())        # padded rows of the short query carry "no match"
+
+
+def test_batches_in_flight_on_separate_streams_equal_serial(dev):
+    """bench.py --inflight: several batches run concurrently on their own HIP streams (workspaces are per stream);
+    every batch must produce exactly what it produces alone."""
+    from pram_amd.pipeline import QueryPipeline
+    sfd2, seg, gml = _models(dev)
+    k = 256
+    pipe = QueryPipeline(sfd2, seg, gml, max_keypoints=k, min_keypoints=8)
+    batches = [torch.stack([W.synthetic_image(10 * j + i, 128, 160) for i in range(3)]).to(dev) for j in range(4)]
+    refs = []
+    for img in batches:
+        ex = sfd2.extract_batched(img, pipe.cfg)
+        refs.append({"descriptors": ex["descriptors"].flip(1).contiguous(), "keypoints": ex["keypoints"].flip(1).contiguous(),
+                     "scores": ex["scores"].flip(1).contiguous(), "lens": ex["counts"].clone()})
+    serial = [QueryPipeline.pack_record(pipe.run(img, ref)).clone() for img, ref in zip(batches, refs)]
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for rep in range(3):                      # a few rounds: a race shows up as a rare mismatch
+        got = []
+        for j, (img, ref) in enumerate(zip(batches, refs)):
+            with torch.cuda.stream(lanes[j % len(lanes)]):
+                got.append(QueryPipeline.pack_record(pipe.run(img, ref)))
+        torch.cuda.synchronize()
+        for a, b in zip(got, serial):
+            assert torch.equal(a, b)
