@@ -70,17 +70,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     }
 }
 
-template <bool CIN4, int MI, int WN>
-__global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
+template <bool CIN4, int MI, int WN, int BKT>
+__global__ __launch_bounds__(gemm::NT, (gemm::Cfg<MI, WN, BKT>::WAVES)) void conv_kernel(ConvArgs p) {
     using namespace gemm;
-    using C = Cfg<MI, WN>;
-    constexpr int BM = C::BM, BN = C::BN;
-    __shared__ Smem<MI, WN> smem;
+    using C = Cfg<MI, WN, BKT>;
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, RPP = C::RPP, KQ = C::KQ;
+    __shared__ Smem<C> smem;
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
     const int tid = threadIdx.x;
-    const int srow = tid >> 3, skq = tid & 7;
+    const int srow = C::stage_row(tid), skq = C::stage_kq(tid);
     const int row0 = tm * BM, col0 = tn * BN;
     const int pad = p.ks >> 1;
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
     bool ok[C::PA];
 #pragma unroll
     for (int pp = 0; pp < C::PA; ++pp) {
-        const int row = row0 + srow + 32 * pp;
+        const int row = row0 + srow + RPP * pp;
         ok[pp] = row < p.m;
         const int rr = ok[pp] ? row : 0;
         const int ox = rr % p.wo;
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
     // loaders: clamped (always legal) addresses + select, no branches around the loads
     const int nlast = p.cout - 1, klast = p.k - 4, ntap = p.ks * p.ks;
     // Wave-uniform walk over K = (ky, kx, ci): advanced incrementally once per chunk (no integer divisions in the loop).
-    // CIN4 (conv1a): a chunk spans 8 taps, one per staging column, so the tap is per-thread (tap = 8 kt + skq <= 15).
+    // CIN4 (conv1a): a chunk spans KQ taps, one per staging column, so the tap is per-thread (tap = KQ kt + skq <= 15).
     int cky = 0, ckx = 0, cci = 0;
     auto adv = [&](int kt) {
         if (CIN4) {
-            const int tap = kt * 8 + skq;
+            const int tap = kt * KQ + skq;
             cky = (tap * 11) >> 5;            // tap / 3 for tap < 16
             ckx = tap - cky * 3;
             cci = 0;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
     };
     const float* brow[C::PB];
 #pragma unroll
-    for (int pp = 0; pp < C::PB; ++pp) brow[pp] = p.w + (size_t)min(col0 + srow + 32 * pp, nlast) * p.k;
+    for (int pp = 0; pp < C::PB; ++pp) brow[pp] = p.w + (size_t)min(col0 + srow + RPP * pp, nlast) * p.k;
     auto la = [&](int pp, int kt) -> float4 {
         const int ky = min(cky, p.ks - 1);
         const int iyc = min(max(iy0[pp] + ky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
@@ -133,10 +133,10 @@ __global__ __launch_bounds__(gemm::NT, 2) void conv_kernel(ConvArgs p) {
         return ok[pp] && cky < p.ks && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
     auto lb = [&](int pp, int kt) -> float4 { return *reinterpret_cast<const float4*>(brow[pp] + min(kt * BK + skq * 4, klast)); };
-    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.cout && (kt * BK + skq * 4) < p.k; };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + RPP * pp) < p.cout && (kt * BK + skq * 4) < p.k; };
 
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (p.k + BK - 1) / BK, acc);
+    mainloop<C, MI>(smem, adv, la, oka, lb, okb, (p.k + BK - 1) / BK, acc);
 
     conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
@@ -330,15 +330,16 @@ extern "C" int pram_conv2d_nhwc_f32(const float* in, int batch, int h, int w, in
     int mi, wn;
     gemm::choose_tile(p.m, cout, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(C4, MI_, WN_)                                                                                  \
-    do {                                                                                                      \
-        p.tiles_m = cdiv(p.m, gemm::Cfg<MI_, WN_>::BM);                                                       \
-        p.tiles_n = cdiv(cout, gemm::Cfg<MI_, WN_>::BN);                                                      \
-        hipLaunchKernelGGL((conv_kernel<C4, MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemm::NT), 0, st, p); \
+    // 64-channel outputs (conv1a, conv1b: short K, write-heavy) take the 16-deep chunk, the deep-K layers the 32-deep one
+#define LAUNCH(C4, MI_, WN_, BK_)                                                                                   \
+    do {                                                                                                            \
+        p.tiles_m = cdiv(p.m, gemm::Cfg<MI_, WN_, BK_>::BM);                                                        \
+        p.tiles_n = cdiv(cout, gemm::Cfg<MI_, WN_, BK_>::BN);                                                       \
+        hipLaunchKernelGGL((conv_kernel<C4, MI_, WN_, BK_>), dim3(p.tiles_m * p.tiles_n), dim3(gemm::NT), 0, st, p); \
     } while (0)
-    if (cin == 4) { if (wn == 1) LAUNCH(true, 2, 1); else LAUNCH(true, 2, 2); }
-    else if (wn == 1) { if (mi == 2) LAUNCH(false, 2, 1); else LAUNCH(false, 1, 1); }
-    else { if (mi == 2) LAUNCH(false, 2, 2); else LAUNCH(false, 1, 2); }
+    if (cin == 4) { if (wn == 1) LAUNCH(true, 2, 1, 16); else LAUNCH(true, 2, 2, 16); }
+    else if (wn == 1) { if (mi == 2) LAUNCH(false, 2, 1, 16); else LAUNCH(false, 1, 1, 16); }
+    else { if (mi == 2) LAUNCH(false, 2, 2, 32); else LAUNCH(false, 1, 2, 32); }
 #undef LAUNCH
     return pram_launch_status("pram_conv2d_nhwc_f32");
 }

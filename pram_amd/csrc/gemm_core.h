@@ -11,9 +11,9 @@
 // (A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]) only require that A and B agree on which k a
 // half-wave supplies, so one ds_read_b128 feeds four MFMAs.
 //
-// LDS rows are padded to 36 floats (144 B): the 16-B slot of row r is 9r + const (mod 16), a
-// bijection over any 16 rows distinct mod 16, so every 16-lane group of ds_read_b128 is
-// conflict-free, and the staging ds_write_b128 (8 lanes = one contiguous 128-B row) is too.
+// LDS rows are padded to BK + 4 floats: the 16-B slot of row r is 9r (BK = 32) or 5r (BK = 16) + const
+// (mod 16), a bijection over any 16 rows distinct mod 16, so every 16-lane group of ds_read_b128 is
+// conflict-free, and the staging ds_write_b128 (KQ lanes = one contiguous row) is too.
 //
 // f32 MFMA runs at the f32 vector rate (64 cycles per 32x32x2 per SIMD): the loop is
 // matrix-pipe bound by a wide margin (64 MFMA = 4096 cycles per chunk per wave against
@@ -24,26 +24,41 @@
 
 namespace gemm {
 
-constexpr int BK = 32, LDT = 36, NT = 256;
+constexpr int NT = 256;
 
 // Tile geometry: 4 waves as WM x WN (WN = 2 or 1), each wave MI x 2 accumulators of 32 x 32:
 //   BM = WM * 32 * MI,  BN = WN * 64.   <2,2> = 128 x 128 (default), <1,2> = 64 x 128 (more, smaller
 //   workgroups when a 128-row grid cannot fill 2 x 256 CU slots), <2,1> = 256 x 64 and <1,1> = 128 x 64
 //   (64-channel outputs: conv1a / conv1b).
-template <int MI, int WN>
+// K chunk BK = 32 or 16.  BK = 16 halves the LDS stage and the staging registers (40 KB, <= 168 VGPRs for
+// <2,2>), which buys a THIRD workgroup per CU (3 waves per SIMD) at the price of twice the barriers: a win
+// where the per-tile overhead counts — the token GEMMs with K = 256..512 (+2..6 %) and the 64-channel
+// convolutions (conv1a: K = 36 pads to 48 instead of 64, 744 -> 447 us) — a small loss (1..8 %) on the deep-K
+// 3x3 convolutions, which keep BK = 32.  The k order of the MFMA sequence is the same either way, so the
+// choice never changes a result bit.
+template <int MI, int WN, int BK_>
 struct Cfg {
+    static_assert(BK_ == 16 || BK_ == 32, "BK");
+    static constexpr int BK = BK_;
+    static constexpr int LDT = BK + 4;        // padded LDS row (floats)
+    static constexpr int KQ = BK / 4;         // float4 slots per row per chunk
+    static constexpr int RPP = NT / KQ;       // rows staged per pass of the 256 threads
+    static constexpr int SUB = BK / 8;        // 8-deep sub-chunks (one ds_read_b128 per operand tile each)
+    static constexpr int WAVES = BK == 16 ? 3 : 2;   // waves per SIMD the kernel is compiled for
     static constexpr int WM = 4 / WN;
     static constexpr int BM = WM * 32 * MI;
     static constexpr int BN = WN * 64;
-    static constexpr int PA = BM / 32;   // float4 staging loads per thread for A
-    static constexpr int PB = BN / 32;   // ... for B
+    static constexpr int PA = BM / RPP;       // float4 staging loads per thread for A
+    static constexpr int PB = BN / RPP;       // ... for B
+    static __device__ __forceinline__ int stage_row(int tid) { return tid / KQ; }
+    static __device__ __forceinline__ int stage_kq(int tid) { return tid % KQ; }
 };
 
-template <int MI, int WN>
+template <class C>
 struct alignas(16) Smem {
-    float a[2][Cfg<MI, WN>::BM * LDT];
-    float b[2][Cfg<MI, WN>::BN * LDT];
-};  // <2,2>: 73,728 B -> two workgroups per CU
+    float a[2][C::BM * C::LDT];
+    float b[2][C::BN * C::LDT];
+};  // <2,2,32>: 73,728 B -> two workgroups per CU; <2,2,16>: 40,960 B -> three
 
 // Guarded staging loads are branch-free and split in two: the loader returns the RAW float4 from an
 // always-legal (clamped) address, and a separate predicate says whether the element is in range.  The
@@ -54,19 +69,19 @@ __device__ __forceinline__ float4 zero_unless(float4 v, bool ok) {
     return v;
 }
 
-// ALoad: float4 operator()(int p, int kt) -> raw A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3]; AOk: its predicate.
+// ALoad: float4 operator()(int p, int kt) -> raw A[row = tid/KQ + RPP*p][kt*BK + (tid%KQ)*4 ..+3]; AOk: its predicate.
 // BLoad / BOk: same for the weight rows.
 // Adv(kt) is called once per chunk before its loads: wave-uniform loader state (e.g. the convolution's current
 // tap / channel offset) advances incrementally there instead of being re-derived with integer divisions per load.
-template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
-__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+template <class C, int MI, class Adv, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
                                          f32x16 (&acc)[MI][2]) {
-    using C = Cfg<MI, WN>;
+    constexpr int WN = C::BN / 64, LDT = C::LDT, RPP = C::RPP, SUB = C::SUB;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
-    const int srow = tid >> 3, skq = tid & 7;
+    const int srow = C::stage_row(tid), skq = C::stage_kq(tid);
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -82,9 +97,9 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
 #pragma unroll
     for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, 0);
 #pragma unroll
-    for (int p = 0; p < C::PA; ++p) *reinterpret_cast<float4*>(&s.a[0][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, 0));
+    for (int p = 0; p < C::PA; ++p) *reinterpret_cast<float4*>(&s.a[0][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, 0));
 #pragma unroll
-    for (int p = 0; p < C::PB; ++p) *reinterpret_cast<float4*>(&s.b[0][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, 0));
+    for (int p = 0; p < C::PB; ++p) *reinterpret_cast<float4*>(&s.b[0][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, 0));
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -124,24 +139,21 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
             }
         };
         fload(0, af[0], bf[0]);
-        fload(1, af[1], bf[1]);
+        if (SUB > 1) fload(1, af[1], bf[1]);
         __builtin_amdgcn_sched_barrier(0);
-        fmma(af[0], bf[0]);
-        fload(2, af[0], bf[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        fmma(af[1], bf[1]);
-        fload(3, af[1], bf[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        fmma(af[0], bf[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        fmma(af[1], bf[1]);
+#pragma unroll
+        for (int kk = 0; kk < SUB; ++kk) {
+            fmma(af[kk & 1], bf[kk & 1]);
+            if (kk + 2 < SUB) fload(kk + 2, af[kk & 1], bf[kk & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (more) {
 #pragma unroll
             for (int p = 0; p < C::PA; ++p)
-                *reinterpret_cast<float4*>(&s.a[cur ^ 1][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, kt + 1));
+                *reinterpret_cast<float4*>(&s.a[cur ^ 1][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, kt + 1));
 #pragma unroll
             for (int p = 0; p < C::PB; ++p)
-                *reinterpret_cast<float4*>(&s.b[cur ^ 1][(srow + 32 * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, kt + 1));
+                *reinterpret_cast<float4*>(&s.b[cur ^ 1][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, kt + 1));
         }
         __syncthreads();
     }

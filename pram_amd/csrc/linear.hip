@@ -94,12 +94,12 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
     }
 }
 
-template <int MI, int WN>
-__global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
+template <int MI, int WN, int BKT>
+__global__ __launch_bounds__(gemm::NT, (gemm::Cfg<MI, WN, BKT>::WAVES)) void linear_kernel(LinArgs p) {
     using namespace gemm;
-    using C = Cfg<MI, WN>;
-    constexpr int BM = C::BM, BN = C::BN;
-    __shared__ Smem<MI, WN> smem;
+    using C = Cfg<MI, WN, BKT>;
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, RPP = C::RPP;
+    __shared__ Smem<C> smem;
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
     float* out = p.out + z * p.so;
     const int K = p.k0 + p.k1;
     const int tid = threadIdx.x;
-    const int srow = tid >> 3, skq = tid & 7;
+    const int srow = C::stage_row(tid), skq = C::stage_kq(tid);
     const int row0 = tm * BM, col0 = tn * BN;
 
     // loaders: clamped (always legal) addresses + select, no branches around the loads; row bases hoisted
@@ -119,24 +119,24 @@ __global__ __launch_bounds__(gemm::NT, 2) void linear_kernel(LinArgs p) {
     const float* brow[C::PB];
 #pragma unroll
     for (int pp = 0; pp < C::PA; ++pp) {
-        const int rc = min(row0 + srow + 32 * pp, mlast);
+        const int rc = min(row0 + srow + RPP * pp, mlast);
         arow0[pp] = a0 + (size_t)rc * p.lda0;
         arow1[pp] = p.a1 ? p.a1 + (size_t)rc * p.lda1 - p.k0 : arow0[pp];
     }
 #pragma unroll
-    for (int pp = 0; pp < C::PB; ++pp) brow[pp] = w + (size_t)min(col0 + srow + 32 * pp, nlast) * K;
+    for (int pp = 0; pp < C::PB; ++pp) brow[pp] = w + (size_t)min(col0 + srow + RPP * pp, nlast) * K;
     auto adv = [](int) {};
     auto la = [&](int pp, int kt) -> float4 {
         const int kc = min(kt * BK + skq * 4, klast);
-        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
+        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % BK == 0
         return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
     };
-    auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + 32 * pp) < p.m && (kt * BK + skq * 4) < K; };
+    auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + RPP * pp) < p.m && (kt * BK + skq * 4) < K; };
     auto lb = [&](int pp, int kt) -> float4 { return *reinterpret_cast<const float4*>(brow[pp] + min(kt * BK + skq * 4, klast)); };
-    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 32 * pp) < p.n && (kt * BK + skq * 4) < K; };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + RPP * pp) < p.n && (kt * BK + skq * 4) < K; };
 
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+    mainloop<C, MI>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
 
     linear_epilogue<MI, WN>(p, acc, out, row0, col0, BM, BN);
 }
@@ -233,19 +233,21 @@ __global__ void fourier_kernel(const float* __restrict__ kpts, const float* __re
     si[idx] = sinf(pr);
 }
 
-template <int MI, int WN>
+template <int MI, int WN, int BKT>
 void launch_linear_t(LinArgs& p, int batch, hipStream_t st) {
-    using C = gemm::Cfg<MI, WN>;
+    using C = gemm::Cfg<MI, WN, BKT>;
     p.tiles_m = cdiv(p.m, C::BM);
     p.tiles_n = cdiv(p.n, C::BN);
-    hipLaunchKernelGGL((linear_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, batch), dim3(gemm::NT), 0, st, p);
+    hipLaunchKernelGGL((linear_kernel<MI, WN, BKT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(gemm::NT), 0, st, p);
 }
 
+// Full grids (>= 512 tiles) take the 16-deep chunk (three workgroups per CU); small ones are latency-bound per
+// workgroup and keep the 32-deep chunk (half the barriers).  The concatenated input needs k0 % BK == 0.
 void launch_linear(LinArgs& p, int batch, hipStream_t st) {
     int mi, wn;
     gemm::choose_tile(p.m * batch, p.n, &mi, &wn);
-    if (wn == 2) { if (mi == 2) launch_linear_t<2, 2>(p, batch, st); else launch_linear_t<1, 2>(p, batch, st); }
-    else         { if (mi == 2) launch_linear_t<2, 1>(p, batch, st); else launch_linear_t<1, 1>(p, batch, st); }
+    if (wn == 2) { if (mi == 2) launch_linear_t<2, 2, 16>(p, batch, st); else launch_linear_t<1, 2, 32>(p, batch, st); }
+    else         { if (mi == 2) launch_linear_t<2, 1, 16>(p, batch, st); else launch_linear_t<1, 1, 32>(p, batch, st); }
 }
 
 template <int MI, int WN>
@@ -287,7 +289,7 @@ extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a
     PRAM_REQUIRE(a0 && w && out, "pram_linear_f32: null pointer");
     PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "pram_linear_f32: bad sizes m=%d n=%d k0=%d k1=%d", m, n, k0, k1);
     PRAM_REQUIRE((k0 + k1) % 4 == 0 && lda0 % 4 == 0, "pram_linear_f32: K and lda must be multiples of 4");
-    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemm::BK == 0 && lda1 % 4 == 0), "pram_linear_f32: concat needs k0 %% 32 == 0");
+    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % 32 == 0 && lda1 % 4 == 0), "pram_linear_f32: concat needs k0 %% 32 == 0");
     if (flags & PRAM_LIN_ROTARY)
         PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
     if (m == 0) return PRAM_OK;
