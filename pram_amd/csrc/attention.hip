@@ -5,7 +5,8 @@
 //
 // Work decomposition: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave
 // owns 32 query rows and walks the keys in tiles of 64 staged through LDS (K XOR-swizzled for
-// conflict-free ds_read_b128, V linear for conflict-free ds_read_b32), double buffered, one
+// conflict-free ds_read_b128, V with its two 32-column halves swapped on rows with key bit 2 set, so the
+// two half-waves of a ds_read_b32 — rows 4 apart — use different banks), double buffered, one
 // barrier per tile.
 //
 // Register-level layout (the point of the design): everything is computed TRANSPOSED so that
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         for (int pp = 0; pp < 4; ++pp) {
             const int row = lrow + 16 * pp;
             *reinterpret_cast<float4*>(&s.k[buf][row * D + ((lslot ^ (row & 15)) << 2)]) = kr[pp];
-            *reinterpret_cast<float4*>(&s.v[buf][row * D + (lslot << 2)]) = vr[pp];
+            *reinterpret_cast<float4*>(&s.v[buf][row * D + ((lslot ^ (((row >> 2) & 1) << 3)) << 2)]) = vr[pp];
         }
     };
 
@@ -224,9 +225,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             auto vload = [&](int t, int e0, float (&vv)[4][2]) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    // bit 2 of the key is h: the two half-waves read rows 4 apart; the 32-column XOR puts them on
+                    // different halves of the 64 banks (a row is exactly 64 banks wide)
                     const int key = t * 32 + key_of(e0 + i, h);
-                    vv[i][0] = sv[key * D + r];
-                    vv[i][1] = sv[key * D + 32 + r];
+                    vv[i][0] = sv[key * D + (r ^ (h << 5))];
+                    vv[i][1] = sv[key * D + ((32 + r) ^ (h << 5))];
                 }
             };
             auto vmma = [&](int t, int e0, const float (&vv)[4][2]) {
