@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 }
             };
             // sched_barrier(0) pins "prefetch, then MFMAs": hipcc otherwise sinks each ds_read next to its use
+            __builtin_amdgcn_s_setprio(3);
             kload(0, kA0, kA1);
 #pragma unroll
             for (int c = 0; c < 8; c += 2) {
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 kmma(c + 1, kB0, kB1);
             }
+            __builtin_amdgcn_s_setprio(0);
             // ---- mask keys beyond klen (last tile of the sequence only)
             if (kt + 1 == nkt_all && (klen & (BKV - 1))) {
                 const int kbase = kt * BKV;
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                     oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[i][1], st[t][e0 + i], oacc[1], 0, 0, 0);
                 }
             };
+            __builtin_amdgcn_s_setprio(3);
             vload(0, 0, vA);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 vmma(t, 12, vB);
             }
+            __builtin_amdgcn_s_setprio(0);
             // ---- end of a key chunk: normalise it, fold it into the running result, start afresh
             if (((kt + 1) % CHUNK_TILES) == 0 || !more) {
                 const float l_c = l_run + __shfl_xor(l_run, 32, 64);

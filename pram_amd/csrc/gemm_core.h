@@ -138,6 +138,8 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
                 }
             }
         };
+        // the matrix phase runs at raised wave priority: the co-resident waves' staging VALU / VMEM bursts then
+        // interleave with this wave's MFMA issue instead of delaying it
         fload(0, af[0], bf[0]);
         if (SUB > 1) fload(1, af[1], bf[1]);
         __builtin_amdgcn_sched_barrier(0);
