@@ -155,12 +155,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    # PRAM_BENCH_ONE_DEVICE=1 (test hook): every rank uses GPU 0 over gloo, to exercise the multi-rank control flow
+    # (barriers, result gather, max-over-ranks timing) on a one-GPU box; never set by the driver
+    one_device = os.environ.get("PRAM_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # backend 'nccl' is RCCL on ROCm
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # backend 'nccl' is RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from pram_amd import ops, weights as Wt
@@ -192,7 +200,14 @@ def main():
         with torch.cuda.stream(lane):
             out = pipe.run(images, ref, stages=args.stages)
             rec = QueryPipeline.pack_record(out)
-            return gather_records(rec)
+        if world == 1:
+            return rec
+        # the (tiny) all-gather stays on the one main stream, in step order on every rank: RCCL never sees
+        # collectives of one communicator issued from several streams
+        main = torch.cuda.current_stream(dev)
+        main.wait_stream(lane)
+        rec.record_stream(main)
+        return gather_records(rec)
 
     def sync_all():
         torch.cuda.synchronize()
