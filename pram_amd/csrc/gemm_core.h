@@ -2,7 +2,7 @@
 // implicit-GEMM convolutions.
 //
 //   C[128 x 128] per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave, 2 x 2 tiles of
-//   v_mfma_f32_32x32x2_f32), K consumed in chunks of 32 through a double-buffered LDS stage.
+//   v_mfma_f32_32x32x2_f32), K consumed in chunks of 32 or 16 through a double-buffered LDS stage.
 //
 // Both operands are "K-contiguous rows" (activations [row][k], weights [col][k]), so A and B
 // fragments use the same LDS image and the same read: lane l (r = l & 31, h = l >> 5) reads one
@@ -13,12 +13,13 @@
 //
 // LDS rows are padded to BK + 4 floats: the 16-B slot of row r is 9r (BK = 32) or 5r (BK = 16) + const
 // (mod 16), a bijection over any 16 rows distinct mod 16, so every 16-lane group of ds_read_b128 is
-// conflict-free, and the staging ds_write_b128 (KQ lanes = one contiguous row) is too.
+// conflict-free; the staging ds_write_b128 (KQ lanes = one contiguous row) is too for BK = 32 (for BK = 16 the
+// PMC pass shows write conflicts; an unpadded XOR-swizzled image that removes them measured slower).
 //
-// f32 MFMA runs at the f32 vector rate (64 cycles per 32x32x2 per SIMD): the loop is
-// matrix-pipe bound by a wide margin (64 MFMA = 4096 cycles per chunk per wave against
-// 16 ds_read_b128 and 8 global float4 loads), so plain register staging with one barrier per
-// chunk is enough; no LDS-DMA or counted-vmcnt pipeline is needed at this rate.
+// f32 MFMA runs at the f32 vector rate (64 cycles per 32x32x2 per SIMD): per 32-deep chunk a wave issues
+// 64 MFMA = 4096 matrix cycles against 16 ds_read_b128 and 8 global float4 loads, so plain register staging
+// with one barrier per chunk is enough; measured MfmaUtil is 64-72 % (profiles/r01_pmc_summary.md), the rest
+// being barrier skew and the per-tile prologue / epilogue of the short-K token GEMMs.
 #pragma once
 #include "common.h"
 
