@@ -74,6 +74,10 @@ def load():
         raise PramHipError(
             f"{_LIB_PATH} not found: build it with `python -m pram_amd.build` "
             "(pram_amd has no CPU / eager fallback)")
+    # PyTorch-ROCm ships its own libamdhip64 and owns the device context the kernels launch into: it has to be the
+    # first HIP runtime in the process.  (Loading this library first binds it to /opt/rocm's copy, and every launch
+    # then fails with "no ROCm-capable device is detected" once torch has initialised its own.)
+    import torch  # noqa: F401
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
