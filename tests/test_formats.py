@@ -80,7 +80,7 @@ def test_open_store_without_h5py_says_so():
 
 
 @pytest.mark.gpu
-def test_match_pairs_batched_equals_reference_loop():
+def test_match_pairs_batched_equals_reference_loop(tmp_path):
     """match_pairs (padded batches, device-side int16 / fp16 casts) == the reference's loop: one pair at a time through
     the plugin, writer_fn's casts (match_features_batch.py:214-228,119-129)."""
     from pram_amd import weights as Wt
@@ -106,3 +106,15 @@ def test_match_pairs_batched_equals_reference_loop():
         want = R.writer_encode({k: v.cpu() for k, v in pred.items()})
         m, s = F.read_matches(out, a, b)
         assert np.array_equal(m, want["matches0"]) and np.array_equal(s.view(np.uint16), want["matching_scores0"].view(np.uint16))
+    # the plugin route (match_from_paths: dynamic_load -> strict checkpoint load -> loop), skipping pairs already stored
+    from pram_amd.localization.match_features_batch import match_from_stores
+    ck = tmp_path / "gml.pth"
+    torch.save({"model": {k: v.cpu() for k, v in net.state_dict().items()}}, ck)
+    out2 = F.DictStore()
+    F.write_matches(out2, F.names_to_pair(*pairs[0][::-1]), {"matches0": np.zeros(3, np.int16)})   # reverse order present -> skipped
+    assert match_from_stores("gml", pairs + [pairs[1]], feats, feats, out2, weight_path=str(ck), device=dev, batch_size=2) == 3
+    for a, b in pairs[1:]:
+        m, s = F.read_matches(out, a, b)
+        m2, s2 = F.read_matches(out2, a, b)
+        assert np.array_equal(m, m2) and np.array_equal(s.view(np.uint16), s2.view(np.uint16))
+    assert F.names_to_pair(*pairs[0]) not in out2
