@@ -91,28 +91,8 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    float4 ra[C::PA], rb[C::PB];
-    adv(0);
-#pragma unroll
-    for (int p = 0; p < C::PA; ++p) ra[p] = la(p, 0);
-#pragma unroll
-    for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, 0);
-#pragma unroll
-    for (int p = 0; p < C::PA; ++p) *reinterpret_cast<float4*>(&s.a[0][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, 0));
-#pragma unroll
-    for (int p = 0; p < C::PB; ++p) *reinterpret_cast<float4*>(&s.b[0][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, 0));
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            adv(kt + 1);
-#pragma unroll
-            for (int p = 0; p < C::PA; ++p) ra[p] = la(p, kt + 1);
-#pragma unroll
-            for (int p = 0; p < C::PB; ++p) rb[p] = lb(p, kt + 1);
-        }
+    // one chunk of matrix work on LDS buffer `cur`
+    auto compute = [&](int cur) {
         const float* sa = &s.a[cur][(wm * 32 * MI + r) * LDT + h * 4];
         const float* sb = &s.b[cur][(wn * 64 + r) * LDT + h * 4];
         // fragments of sub-chunk kk+1 are read from LDS before the MFMAs of kk (pinned with sched_barrier:
@@ -139,8 +119,6 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
                 }
             }
         };
-        // the matrix phase runs at raised wave priority: the co-resident waves' staging VALU / VMEM bursts then
-        // interleave with this wave's MFMA issue instead of delaying it
         fload(0, af[0], bf[0]);
         if (SUB > 1) fload(1, af[1], bf[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -150,14 +128,38 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
             if (kk + 2 < SUB) fload(kk + 2, af[kk & 1], bf[kk & 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
+    };
+    // staging: issue() starts the global loads of a chunk into a register set and records its predicates (from the
+    // addresses only: nothing waits on the data); commit() zero-fills by predicate and writes the set to an LDS buffer
+    auto issue = [&](int kt, float4 (&ra)[C::PA], float4 (&rb)[C::PB], unsigned& ok) {
+        adv(kt);
+        ok = 0u;
 #pragma unroll
-            for (int p = 0; p < C::PA; ++p)
-                *reinterpret_cast<float4*>(&s.a[cur ^ 1][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(ra[p], oka(p, kt + 1));
+        for (int p = 0; p < C::PA; ++p) { ra[p] = la(p, kt); ok |= (oka(p, kt) ? 1u : 0u) << p; }
 #pragma unroll
-            for (int p = 0; p < C::PB; ++p)
-                *reinterpret_cast<float4*>(&s.b[cur ^ 1][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(rb[p], okb(p, kt + 1));
-        }
+        for (int p = 0; p < C::PB; ++p) { rb[p] = lb(p, kt); ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+    };
+    auto commit = [&](int buf, const float4 (&ra)[C::PA], const float4 (&rb)[C::PB], unsigned ok) {
+#pragma unroll
+        for (int p = 0; p < C::PA; ++p)
+            *reinterpret_cast<float4*>(&s.a[buf][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(ra[p], (ok >> p) & 1u);
+#pragma unroll
+        for (int p = 0; p < C::PB; ++p)
+            *reinterpret_cast<float4*>(&s.b[buf][(srow + RPP * p) * LDT + skq * 4]) = zero_unless(rb[p], (ok >> (8 + p)) & 1u);
+    };
+
+    // chunk kt+1 is loaded under the MFMAs of chunk kt.  (Issuing chunk kt+2 there instead — two register sets, same
+    // LDS double buffer — was measured for the 16-deep chunks: within +-1 % everywhere, +1.5 % only at K = 4096.)
+    float4 ra[C::PA], rb[C::PB];
+    unsigned ok;
+    issue(0, ra, rb, ok);
+    commit(0, ra, rb, ok);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) issue(kt + 1, ra, rb, ok);
+        compute(kt & 1);
+        if (more) commit((kt + 1) & 1, ra, rb, ok);
         __syncthreads();
     }
 }
