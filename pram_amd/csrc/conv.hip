@@ -103,7 +103,7 @@ __global__ __launch_bounds__(gemm::NT, (gemm::Cfg<MI, WN, BKT>::WAVES)) void con
     }
 
     // loaders: clamped (always legal) addresses + select, no branches around the loads
-    const int nlast = p.cout - 1, klast = p.k - 4, ntap = p.ks * p.ks;
+    const int nlast = p.cout - 1, klast = p.k - 4;
     // Wave-uniform walk over K = (ky, kx, ci): advanced incrementally once per chunk (no integer divisions in the loop).
     // CIN4 (conv1a): a chunk spans KQ taps, one per staging column, so the tap is per-thread (tap = KQ kt + skq <= 15).
     int cky = 0, ckx = 0, cci = 0;

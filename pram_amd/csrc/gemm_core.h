@@ -46,6 +46,7 @@ struct Cfg {
     static constexpr int RPP = NT / KQ;       // rows staged per pass of the 256 threads
     static constexpr int SUB = BK / 8;        // 8-deep sub-chunks (one ds_read_b128 per operand tile each)
     static constexpr int WAVES = BK == 16 ? 3 : 2;   // waves per SIMD the kernel is compiled for
+    static constexpr bool INTERLEAVE = BK == 32;     // staging issue interleaved with the first MFMA group (see mainloop)
     static constexpr int WM = 4 / WN;
     static constexpr int BM = WM * 32 * MI;
     static constexpr int BN = WN * 64;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     // one chunk of matrix work on LDS buffer `cur`
-    auto compute = [&](int cur) {
+    auto compute = [&](int cur, auto&& stage) {
         const float* sa = &s.a[cur][(wm * 32 * MI + r) * LDT + h * 4];
         const float* sb = &s.b[cur][(wn * 64 + r) * LDT + h * 4];
         // fragments of sub-chunk kk+1 are read from LDS before the MFMAs of kk (pinned with sched_barrier:
@@ -122,8 +123,26 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
         fload(0, af[0], bf[0]);
         if (SUB > 1) fload(1, af[1], bf[1]);
         __builtin_amdgcn_sched_barrier(0);
+        // INTERLEAVE (BK = 32, two waves per SIMD): `stage` holds the next chunk's address arithmetic and global loads,
+        // issued in the shadow of the first MFMA group — one load and a few VALU per two MFMAs — instead of in one
+        // burst before the matrix work (-3..5 % on the deep-K convolutions).  With three waves per SIMD (BK = 16) the
+        // burst is already covered by the other waves and the interleaved order measured 3-10 % slower: there the
+        // caller issues the loads before compute() and passes an empty `stage`.
+        stage();
+        fmma(af[0], bf[0]);
+        if (2 < SUB) fload(2, af[0], bf[0]);
+        if constexpr (C::INTERLEAVE) {
 #pragma unroll
-        for (int kk = 0; kk < SUB; ++kk) {
+            for (int g = 0; g < 2 * MI; ++g) {            // pattern found by measurement; what does not fit it follows
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU (address arithmetic)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 global load
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 1; kk < SUB; ++kk) {
             fmma(af[kk & 1], bf[kk & 1]);
             if (kk + 2 < SUB) fload(kk + 2, af[kk & 1], bf[kk & 1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -132,7 +151,6 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
     // staging: issue() starts the global loads of a chunk into a register set and records its predicates (from the
     // addresses only: nothing waits on the data); commit() zero-fills by predicate and writes the set to an LDS buffer
     auto issue = [&](int kt, float4 (&ra)[C::PA], float4 (&rb)[C::PB], unsigned& ok) {
-        adv(kt);
         ok = 0u;
 #pragma unroll
         for (int p = 0; p < C::PA; ++p) { ra[p] = la(p, kt); ok |= (oka(p, kt) ? 1u : 0u) << p; }
@@ -152,13 +170,20 @@ __device__ __forceinline__ void mainloop(Smem<C>& s, Adv& adv, ALoad& la, AOk& o
     // LDS double buffer — was measured for the 16-deep chunks: within +-1 % everywhere, +1.5 % only at K = 4096.)
     float4 ra[C::PA], rb[C::PB];
     unsigned ok;
+    adv(0);
     issue(0, ra, rb, ok);
     commit(0, ra, rb, ok);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) issue(kt + 1, ra, rb, ok);
-        compute(kt & 1);
+        if (more) adv(kt + 1);
+        if constexpr (C::INTERLEAVE) {
+            const int lk = more ? kt + 1 : kt;   // the last iteration re-issues its own (legal) addresses: no branch in the region
+            compute(kt & 1, [&] { issue(lk, ra, rb, ok); });
+        } else {
+            if (more) issue(kt + 1, ra, rb, ok);
+            compute(kt & 1, [] {});
+        }
         if (more) commit((kt + 1) & 1, ra, rb, ok);
         __syncthreads();
     }
