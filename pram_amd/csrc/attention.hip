@@ -109,23 +109,21 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 
     const int lrow = tid >> 4, lslot = tid & 15;   // staging: row lrow + 16p, 16-B slot lslot
     float4 kr[4], vr[4];
+    // staging loads are branch-free (clamped, always-legal row; rows >= klen are zeroed when they go to LDS), so
+    // they can be scheduled in between the first MFMAs of the tile instead of in a burst in front of them
     auto gload = [&](int kt) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            const int key = kt * BKV + lrow + 16 * pp;
-            if (key < klen) {
-                kr[pp] = *reinterpret_cast<const float4*>(kp + (size_t)key * p.ldk + lslot * 4);
-                vr[pp] = *reinterpret_cast<const float4*>(vp + (size_t)key * p.ldv + lslot * 4);
-            } else {
-                kr[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-                vr[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const int key = min(kt * BKV + lrow + 16 * pp, klen - 1);
+            kr[pp] = *reinterpret_cast<const float4*>(kp + (size_t)key * p.ldk + lslot * 4);
+            vr[pp] = *reinterpret_cast<const float4*>(vp + (size_t)key * p.ldv + lslot * 4);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int kt) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             const int row = lrow + 16 * pp;
+            if (kt * BKV + row >= klen) { kr[pp] = make_float4(0.f, 0.f, 0.f, 0.f); vr[pp] = kr[pp]; }
             *reinterpret_cast<float4*>(&s.k[buf][row * D + ((lslot ^ (row & 15)) << 2)]) = kr[pp];
             *reinterpret_cast<float4*>(&s.v[buf][row * D + ((lslot ^ (((row >> 2) & 1) << 3)) << 2)]) = vr[pp];
         }
@@ -137,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const int nkt = p.nsplit > 1 ? min(nkt_all, kt0 + CHUNK_TILES) : nkt_all;   // one past its last tile
     if (kt0 >= nkt) return;                                                // this chunk lies beyond klen
     gload(kt0);
-    lstore(kt0 & 1);
+    lstore(kt0 & 1, kt0);
     __syncthreads();
 
     float m_run = -1.0e30f, l_run = 0.f;
@@ -151,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     for (int kt = kt0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) gload(kt + 1);
+        const int lt = more ? kt + 1 : kt;     // the last tile re-issues its own (legal) rows: no branch in the MFMA region
+        if (!wave_active) gload(lt);
 
         if (wave_active) {
             // ---- Sᵀ = K · Qᵀ for the two 32-key sub-tiles
@@ -180,8 +179,23 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             // sched_barrier(0) pins "prefetch, then MFMAs": hipcc otherwise sinks each ds_read next to its use
             __builtin_amdgcn_s_setprio(3);
             kload(0, kA0, kA1);
+            kload(1, kB0, kB1);
+            __builtin_amdgcn_sched_barrier(0);
+            // next tile's K / V rows: 8 global loads + their address arithmetic, two per pair of MFMAs of the first chunk
+            gload(lt);
+            kmma(0, kA0, kA1);
 #pragma unroll
-            for (int c = 0; c < 8; c += 2) {
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            kload(2, kA0, kA1);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(1, kB0, kB1);
+#pragma unroll
+            for (int c = 2; c < 8; c += 2) {
                 kload(c + 1, kB0, kB1);
                 __builtin_amdgcn_sched_barrier(0);
                 kmma(c, kA0, kA1);
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
             }
         }
-        if (more) lstore(cur ^ 1);
+        if (more) lstore(cur ^ 1, kt + 1);
         __syncthreads();
     }
 
