@@ -78,6 +78,11 @@ struct Smem {
 
 __device__ __forceinline__ int key_of(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
+// Softmax exponentials: arguments are <= 0 and results in [0, 1], so the bare v_exp_f32 is enough.  exp2f() wraps
+// it in a denormal-range rescue (compare, two selects, add, ldexp: 6 instructions instead of 1) that only matters
+// for probabilities below 2^-126; that wrapper was half of the softmax's VALU work (attention 121 -> 128 TFLOP/s).
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     __shared__ Smem s;
     const int nblk = p.batch * p.heads * p.q_tiles;
@@ -221,13 +226,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax * p.scale2);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = fast_exp2(m_run - m_new);
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = exp2f(fmaf(st[t][e], p.scale2, -m_new));
+                    const float pv = fast_exp2(fmaf(st[t][e], p.scale2, -m_new));
                     st[t][e] = pv;
                     psum += pv;
                 }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
                 const int qi = qt * BKV + t * 32 + r;
                 const float l2 = (qi < qlen) ? lse[qi] : INFINITY;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) cacc[e] += exp2f(fmaf(st[e], p.scale2, -l2));
+                for (int e = 0; e < 16; ++e) cacc[e] += fast_exp2(fmaf(st[e], p.scale2, -l2));
             }
             __syncthreads();
         }
