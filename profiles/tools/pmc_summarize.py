@@ -35,10 +35,10 @@ with open(os.path.join(root, "profiles", f"{tag}_pmc_summary.md"), "w") as o:
             "`rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 1 --warmup 1 --cpu-queries 0`, one counter set per run.\n"
             "`MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024)`; `hbm_read = 2 x FETCH_SIZE KB` (gfx950 correction); "
             "`hbm_write = WRITE_SIZE KB` (uncalibrated).\n\n"
-            "| kernel | launches | avg us | MfmaUtil % | FETCH_SIZE KB | hbm_read MiB | WRITE_SIZE KB | SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS | SQ_WAIT_INST_ANY / WAVE_CYCLES |\n|---|---|---|---|---|---|---|---|---|\n")
+            "| kernel | launches | avg us | MfmaUtil % | FETCH_SIZE KB | hbm_read MiB | WRITE_SIZE KB | HBM GB/s (read+write) | SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS | SQ_WAIT_INST_ANY / WAVE_CYCLES |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for r in rows[:32]:
         o.write(f"| {r['kernel'][:60]} | {r['launches']} | {r['avg_us']:.1f} | {r['mfma']:.1f} | {r['fetch_kb']:.0f} | "
-                f"{2 * r['fetch_kb'] / 1024:.1f} | {r['write_kb']:.0f} | {r['lds']:.2f} | {r['wait']:.2f} |\n")
+                f"{2 * r['fetch_kb'] / 1024:.1f} | {r['write_kb']:.0f} | {(2 * r['fetch_kb'] + r['write_kb']) * 1024 / (r['avg_us'] * 1e3):.0f} | {r['lds']:.2f} | {r['wait']:.2f} |\n")
 att = next((r for r in rows if r["kernel"].startswith("attention_kernel")), None)
 if att:
     js = {"attention_kernel": {"hbm_bytes_per_launch": (2 * att["fetch_kb"] + att["write_kb"]) * 1024, "fetch_size_kb": att["fetch_kb"],
