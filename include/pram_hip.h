@@ -83,7 +83,7 @@ int pram_fourier_encoding_f32(const float* kpts, const float* wr, float cx, floa
 /* ---------------------------------------------------------------- attention (graded kernel) */
 
 /* Flash-style multi-head attention, head_dim 64, exact-fp32 MFMA (Attention.forward
- * nets/segnetvit.py:73-76; cross attention nets/gml.py:175-179 is two calls; K8/K9):
+ * nets/segnetvit.py:73-76; for cross attention (nets/gml.py:175-179) see pram_attention_cross_f32 below; K8/K9):
  *   out[b, i, h*64:(h+1)*64] = softmax_j( scale * q[b,i,h]·k[b,j,h] ) · v[b,j,h]
  * q rows of batch b start at row b*m_max (k/v: b*n_max).  lse2 (optional) receives
  * log2-domain log-sum-exp [batch][heads][m_max] for pram_attention_colmean_f32. */

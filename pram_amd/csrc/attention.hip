@@ -1,6 +1,6 @@
 // Flash-style multi-head attention in exact fp32 on the gfx950 matrix cores
 // (v_mfma_f32_32x32x2_f32).  Replaces the materialised einsum -> softmax -> einsum of
-// nets/segnetvit.py:73-76 (self), nets/gml.py:175-179 (cross; two calls) and the column means of
+// nets/segnetvit.py:73-76 (self), nets/gml.py:175-179 (cross: both directions in one launch, kv_shift) and the column means of
 // nets/adagml.py:148,229.
 //
 // Work decomposition: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave
