@@ -443,6 +443,33 @@ def gen_edges(ref):
             assert np.array_equal(rk, ok_) and np.abs(rs - os_).max() < 1e-7 and np.abs(rd - od_).max() < 1e-5, tag
             print(f"  extract_sfd2_return {tag}: {len(rk)} keypoints")
             save(f"sfd2_offline_{tag}", keypoints=rk, scores=rs, descriptors_sub=rd[:, ::8], **{k: np.array(v) for k, v in kw.items()})
+        # mask-labelled variant (sfd2.py:508-571).  Harness shim: the reference spells float64 as np.float, which numpy >= 1.24
+        # no longer has.  Segmentation ids: vertical bands, band 0 unlabelled; the three topK regimes + topK = -1.
+        if not hasattr(np, "float"):
+            np.float = float
+        mask = np.zeros((96, 128, 3), np.uint8)
+        for band, (b_, g_, r_) in enumerate([(0, 0, 0), (7, 0, 0), (0, 3, 0), (5, 1, 2)]):
+            mask[:, band * 32:(band + 1) * 32] = (b_, g_, r_)
+        full = R.extract_sfd2_return(sd2, raw.clone(), conf_th=0.001, topK=-1)
+        n_all = len(full["scores"])
+        n_lab = int((full["keypoints"][:, 0] >= 32).sum())
+        for tag, topk in {"few": max(1, n_lab // 2), "all": n_all + 10, "mix": n_lab + (n_all - n_lab) // 2, "none": -1}.items():
+            r = s.extract_sfd2_return(net, raw.clone(), conf_th=0.001, mask=mask, topK=topk)
+            o = R.extract_sfd2_return(sd2, raw.clone(), conf_th=0.001, mask=mask, topK=topk)
+            assert r["labels"].dtype == np.int32 and len(r["labels"]) == len(o["labels"]), tag
+            # same multiset of (keypoint, label) records; order equal up to the reference's unstable ties
+            def canon(d):
+                n = len(d["labels"]) if tag != "none" else None
+                lab = d["labels"] if tag != "none" else np.zeros(len(d["scores"]), np.int32)
+                key = np.lexsort((d["keypoints"][:, 0], d["keypoints"][:, 1], -d["scores"], -(lab != 0).astype(int)))
+                return d["keypoints"][key], d["scores"][key], lab[key], d["descriptors"][key]
+            for a, b in zip(canon(r), canon(o)):
+                assert np.abs(np.asarray(a, float) - np.asarray(b, float)).max() < 1e-5, tag
+            if tag == "none":
+                assert np.array_equal(np.sort(r["labels"]), np.sort(o["labels"]))
+            print(f"  extract_sfd2_return mask/{tag}: topK {topk} -> {len(o['scores'])} keypoints, {len(o['labels'])} labels")
+            save(f"sfd2_offline_mask_{tag}", keypoints=o["keypoints"], scores=o["scores"], labels=o["labels"],
+                 descriptors_sub=o["descriptors"][:, ::8], topK=np.array(topk), mask_bands=np.array([[0, 0, 0], [7, 0, 0], [0, 3, 0], [5, 1, 2]]))
     finally:
         torch.Tensor.cuda = orig_cuda
 

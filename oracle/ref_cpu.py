@@ -571,8 +571,42 @@ def match_by_projection(q_kpts, q_descs, proj_uvs, ref_descs, threshold: float):
     return (ratios <= 0.995) & (dists[:, 0] < 100), ids[:, 0], dists
 
 
-def extract_sfd2_return(sd: SD, img: torch.Tensor, conf_th=0.001, topK=-1, scales=(1.0,)):
-    """extract_sfd2_return — nets/sfd2.py:386-589 (mask=None path).  img [1,3,H,W] in [0,1], un-normalised."""
+def mask_labelling(keypoints, scores, descriptors, mask, topK=-1) -> dict:
+    """extract_sfd2_return's mask branch — nets/sfd2.py:508-571, kept as the reference's per-keypoint loop.  Ties in the
+    two score sorts are broken by (score desc, index asc) instead of numpy's unspecified quicksort order."""
+    labels, others = [], []
+    kp_l, sc_l, de_l, kp_u, sc_u, de_u = [], [], [], [], [], []
+    id_img = np.int32(mask[:, :, 2]) * 256 * 256 + np.int32(mask[:, :, 1]) * 256 + np.int32(mask[:, :, 0])
+    for i in range(keypoints.shape[0]):
+        x, y = keypoints[i, 0], keypoints[i, 1]
+        gid = id_img[int(y), int(x)]
+        if gid == 0:
+            kp_u.append(keypoints[i]); sc_u.append(scores[i]); de_u.append(descriptors[i]); others.append(0)
+        else:
+            kp_l.append(keypoints[i]); sc_l.append(scores[i]); de_l.append(descriptors[i]); labels.append(gid)
+    if topK > 0:
+        if topK <= len(kp_l):
+            idxes = np.argsort(-np.array(sc_l, float), kind="stable")[:topK]
+            keypoints = np.array(kp_l, float)[idxes]
+            scores = np.array(sc_l, float)[idxes]
+            labels = np.array(labels, np.int32)[idxes]
+            descriptors = np.array(de_l, float)[idxes]
+        elif topK >= len(kp_l) + len(kp_u):
+            keypoints, scores, descriptors = kp_l, sc_l, de_l
+            for i in range(len(others)):
+                keypoints.append(kp_u[i]); scores.append(sc_u[i]); descriptors.append(de_u[i]); labels.append(others[i])
+        else:
+            n = topK - len(kp_l)
+            idxes = np.argsort(-np.array(sc_u, float), kind="stable")[:n]
+            keypoints, scores, descriptors = kp_l, sc_l, de_l
+            for i in idxes:
+                keypoints.append(kp_u[i]); scores.append(sc_u[i]); descriptors.append(de_u[i]); labels.append(others[i])
+    return {"keypoints": np.array(keypoints, float), "descriptors": np.array(descriptors, float),
+            "scores": np.array(scores, float), "labels": np.array(labels, np.int32)}
+
+
+def extract_sfd2_return(sd: SD, img: torch.Tensor, conf_th=0.001, topK=-1, scales=(1.0,), mask=None):
+    """extract_sfd2_return — nets/sfd2.py:386-589.  img [1,3,H,W] in [0,1], un-normalised."""
     mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
     img = ((img.squeeze() - mean) / std)[None]
@@ -605,6 +639,8 @@ def extract_sfd2_return(sd: SD, img: torch.Tensor, conf_th=0.001, topK=-1, scale
         return None, None, None
     pts, descs = np.vstack(all_pts), np.vstack(all_descs)
     kp, scs = pts[:, :2], pts[:, 2]
+    if mask is not None:
+        return mask_labelling(kp, scs, descs, mask, topK)
     if topK > 0:
         idx = np.argsort(-np.array(scs, dtype=float), kind="stable")[:topK]
         kp, scs, descs = kp[idx], scs[idx], descs[idx]

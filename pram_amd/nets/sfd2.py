@@ -218,6 +218,37 @@ def load_sfd2(weight_path):
 
 
 @torch.no_grad()
+def label_keypoints_by_mask(keypoints, scores, descriptors, mask, topK=-1):
+    """The mask branch of extract_sfd2_return (nets/sfd2.py:508-571): a keypoint's label is the 24-bit id the BGR
+    segmentation image holds at (int(y), int(x)); labelled keypoints come first, the budget ``topK`` is filled with
+    the best labelled ones, then with the best unlabelled ones (label 0).  Host-side numpy, like the reference.
+    Reproduced as they are: with topK <= 0 all keypoints come back in their original order while ``labels`` lists
+    only the labelled ones; score ties follow (score desc, original index asc) (numpy's default argsort leaves them
+    unspecified); the reference's ``np.float`` (gone from numpy >= 1.24) is float64."""
+    import numpy as np
+    mask = np.asarray(mask)
+    id_img = np.int32(mask[:, :, 2]) * 256 * 256 + np.int32(mask[:, :, 1]) * 256 + np.int32(mask[:, :, 0])
+    keypoints, scores, descriptors = np.asarray(keypoints), np.asarray(scores), np.asarray(descriptors)
+    gid = id_img[keypoints[:, 1].astype(np.int64), keypoints[:, 0].astype(np.int64)]      # int(): truncation, coordinates >= 0
+    lab, unl = np.flatnonzero(gid != 0), np.flatnonzero(gid == 0)
+    labels = gid[lab].astype(np.int32)
+    best = lambda idx, n: idx[np.argsort(-scores[idx].astype(float), kind="stable")[:n]]
+    if topK > 0:
+        if topK <= lab.size:
+            sel = best(lab, topK)
+            labels = gid[sel].astype(np.int32)
+        elif topK >= lab.size + unl.size:
+            sel = np.concatenate([lab, unl])
+            labels = np.concatenate([labels, np.zeros(unl.size, np.int32)])
+        else:
+            extra = best(unl, topK - lab.size)
+            sel = np.concatenate([lab, extra])
+            labels = np.concatenate([labels, np.zeros(extra.size, np.int32)])
+        keypoints, scores, descriptors = keypoints[sel], scores[sel], descriptors[sel]
+    return {"keypoints": np.array(keypoints, float), "descriptors": np.array(descriptors, float),
+            "scores": np.array(scores, float), "labels": np.array(labels, np.int32)}
+
+
 def extract_sfd2_return(model, img, conf_th=0.001, mask=None, topK=-1, min_keypoints=0, **kwargs):
     """Offline extraction variant (nets/sfd2.py:386-589): det() per scale, NMS radius 3, ``>`` threshold,
     sort by score, border 4, descriptors at the keypoints, float64 numpy outputs.  The dense work (convs,
@@ -270,7 +301,7 @@ def extract_sfd2_return(model, img, conf_th=0.001, mask=None, topK=-1, min_keypo
     all_pts, all_descs = np.vstack(all_pts), np.vstack(all_descs)
     keypoints, scores, descriptors = all_pts[:, 0:2], all_pts[:, 2], all_descs
     if mask is not None:
-        raise NotImplementedError("mask-labelled extraction (nets/sfd2.py:508-571) belongs to offline map building")
+        return label_keypoints_by_mask(keypoints, scores, descriptors, mask, topK)
     if topK > 0:
         idxes = np.argsort(-np.array(scores, dtype=float), kind="stable")[:topK]
         keypoints, scores, descriptors = keypoints[idxes], scores[idxes], descriptors[idxes]

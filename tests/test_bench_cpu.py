@@ -9,6 +9,10 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def test_bench_refuses_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this host has a GPU: bench.py runs here (tests/test_gpu_bench.py covers that)")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)
 

