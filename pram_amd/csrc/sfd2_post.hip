@@ -468,8 +468,10 @@ extern "C" int pram_select_keypoints_f32(const float* nms, int batch, int h, int
                                          int border, int max_keypoints, int fallback_ref, float* kpts, float* scores,
                                          int* counts, void* workspace, void* stream) {
     PRAM_REQUIRE(nms && kpts && scores && counts && workspace, "pram_select_keypoints_f32: null pointer");
-    PRAM_REQUIRE(max_keypoints > 0 && max_keypoints <= SEL_KMAX, "pram_select_keypoints_f32: max_keypoints=%d not in (0, %d]",
-                 max_keypoints, SEL_KMAX);
+    // a bound >= h*w can never be exceeded ("keep all", nets/sfd2.py:324 with max_keypoints < 0): the in-LDS top-k
+    // sort, which is what limits the bound to SEL_KMAX, is then unreachable
+    PRAM_REQUIRE((max_keypoints > 0 && max_keypoints <= SEL_KMAX) || max_keypoints >= h * w,
+                 "pram_select_keypoints_f32: max_keypoints=%d not in (0, %d] and not >= h*w (keep all)", max_keypoints, SEL_KMAX);
     PRAM_REQUIRE(fallback_ref < batch, "pram_select_keypoints_f32: fallback_ref out of range");
     PRAM_REQUIRE(conf_th > 0.f, "pram_select_keypoints_f32: conf_th must be positive");
     if (batch == 0) return PRAM_OK;

@@ -165,9 +165,16 @@ class ResNet4x(blk.PackedCache, nn.Module):
             score = ops.resize_bilinear(score, ih, iw)
         nms = ops.simple_nms(score, 4)
         if cfg['max_keypoints'] < 0:
-            raise NotImplementedError("max_keypoints < 0 (keep all) is not supported; pass a bound")
-        kpts, scores, counts = ops.select_keypoints(nms, cfg['conf_th'], cfg['min_keypoints'], cfg['remove_borders'],
-                                                    cfg['max_keypoints'], -1 if per_image_fallback else 0)
+            # keep every candidate in nonzero() (row-major) order (nets/sfd2.py:324 skips top_k_keypoints): select with a
+            # bound that cannot be exceeded, then trim the padded buffers to the longest set — one host read of the
+            # counts, which the reference pays in nonzero() as well
+            kpts, scores, counts = ops.select_keypoints(nms, cfg['conf_th'], cfg['min_keypoints'], cfg['remove_borders'],
+                                                        ih * iw, -1 if per_image_fallback else 0)
+            k_eff = max(int(counts.max().item()), 1)
+            kpts, scores = kpts[:, :k_eff].contiguous(), scores[:, :k_eff].contiguous()
+        else:
+            kpts, scores, counts = ops.select_keypoints(nms, cfg['conf_th'], cfg['min_keypoints'], cfg['remove_borders'],
+                                                        cfg['max_keypoints'], -1 if per_image_fallback else 0)
         desc_map = self._desc_head(P, o4)
         descs = ops.sample_nhwc(desc_map, kpts, counts, 4, True)
         return dict(score_map=score, desc_map=desc_map, mid_features=o4, global_nhwc=[o1b, o2b, o3b, o4],

@@ -94,6 +94,32 @@ def test_select_keypoints_max_k_and_border_only(dev):
     assert ops.select_keypoints(z.to(dev), 0.005, 0, 4, 100, fallback_ref=0)[2].tolist() == [0]
 
 
+def test_keep_all_keypoints(dev):
+    """max_keypoints < 0 keeps every candidate in nonzero() order (nets/sfd2.py:324 skips top_k_keypoints): selection
+    bit-exact against the oracle on the same NMS map (more than the 8192 an in-LDS top-k could hold), and through the
+    model API."""
+    from pram_amd import ops
+    from pram_amd.nets.sfd2 import ResNet4x
+    s = torch.floor(W.uniform(28, "sel/all", (2, 120, 160), 0.0, 64.0)) / 64.0 * 0.9 + 0.01
+    s[1, :, 80:] = 0.0
+    kps, scs = R.select_keypoints(s, 0.005, 10, 4, -1, per_image_fallback=True)
+    assert len(kps[0]) == 112 * 152 > 8192
+    kp, sc, cnt = ops.select_keypoints(s.to(dev).contiguous(), 0.005, 10, 4, 120 * 160, fallback_ref=-1)
+    assert cnt.tolist() == [len(k) for k in kps]
+    for b in range(2):
+        assert torch.equal(kp[b, :cnt[b]].cpu(), kps[b]) and torch.equal(sc[b, :cnt[b]].cpu(), scs[b])
+    net = ResNet4x()
+    net.load_state_dict(H.sfd2_sd(), strict=True)
+    net = net.to(dev).eval()
+    img = W.synthetic_image(6, 96, 128)[None]
+    o = R.sfd2_extract_local_global(H.sfd2_sd(), img, max_keypoints=-1, min_keypoints=8)
+    r = net.extract_local_global({"image": img.to(dev)}, {"max_keypoints": -1, "min_keypoints": 8})
+    n = len(o["keypoints"][0])
+    assert abs(len(r["keypoints"][0]) - n) <= max(2, n // 50)
+    same = (r["keypoints"][0].cpu()[:, None, :] == o["keypoints"][0][None]).all(-1).any(1).float().mean().item()
+    assert same > 0.95 and tuple(r["descriptors"][0].shape) == (128, len(r["keypoints"][0]))
+
+
 def test_nms_radius_zero_and_non_multiple_tile(dev):
     from pram_amd import ops
     s = W.uniform(27, "nms/odd", (2, 45, 77), 0.0, 1.0)
