@@ -215,7 +215,9 @@ size_t pram_select_keypoints_workspace_bytes(int batch, int h, int w, int max_ke
  * Canonical order: if more than max_keypoints candidates survive, (score desc, flat index asc);
  * otherwise row-major.  fallback_ref: -1 = each image tests its own count (per-query
  * semantics), >= 0 = every image uses that image's count (reference tests element 0).
- * kpts [b][max_keypoints][2] (x,y) fp32, scores [b][max_keypoints], counts [b]. */
+ * kpts [b][max_keypoints][2] (x,y) fp32, scores [b][max_keypoints], counts [b].
+ * max_keypoints is in (0, 8192] (the top-k is sorted in LDS) or >= h*w (= keep all: the reference's
+ * max_keypoints < 0, nets/sfd2.py:324; row-major order, never sorted). */
 int pram_select_keypoints_f32(const float* nms, int batch, int h, int w, float conf_th,
                               int min_keypoints, int border, int max_keypoints, int fallback_ref,
                               float* kpts, float* scores, int* counts, void* workspace, void* stream);
