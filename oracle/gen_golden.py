@@ -108,6 +108,21 @@ def gen_segnetvit(ref):
              logits_rows=out_ref[:, :8].numpy())
 
 
+    # with_sc head (no shipped config enables it): 3 layers, one small frame
+    seg = ref["segvit"].SegNetViT({"n_class": 21, "n_layers": 3, "with_sc": True, "hidden_dim": 256, "output_dim": 1024}).eval()
+    sd = W.make_state_dict("segnetvit", seg.state_dict(), seed=7)
+    seg.load_state_dict(sd, strict=True)
+    d0, k0 = W.synthetic_tokens(9, 200)[:2]
+    img = torch.empty(1, 3, 480, 640)
+    with torch.no_grad():
+        r = seg({"seg_descriptors": d0[None], "keypoints": k0[None], "image": img})
+        probes = {}
+        o = R.segnetvit_forward(sd, d0[None], k0[None], img.shape, n_layers=3, probes=probes)
+    assert maxdiff(r["prediction"], o) < 2e-5 and maxdiff(r["sc"], probes["sc"]) < 2e-5
+    print(f"  with_sc: |ref - oracle|max prediction {maxdiff(r['prediction'], o):.2e}, sc {maxdiff(r['sc'], probes['sc']):.2e}")
+    save("segnetvit_with_sc", sc=r["sc"].numpy(), prediction_rows=r["prediction"][:, :8].numpy(), n_class=21, n_layers=3, N=200)
+
+
 def gen_sinkhorn(ref):
     print("Sinkhorn / dual-softmax / compute_matches")
     g = ref["gml"]

@@ -143,6 +143,8 @@ def segnetvit_forward(sd: SD, seg_descriptors: torch.Tensor, keypoints: Optional
         x = self_block(sd, f"gnn.layers.{i}", x, cos, sin, heads)
         if probes is not None:
             probes[f"layer{i}"] = x
+    if probes is not None and "sc.0.weight" in sd:      # with_sc head on the same tokens — nets/segnetvit.py:166-172,199-201
+        probes["sc"] = _lin(sd, "sc.3", _ln_gelu(sd, "sc.1", _lin(sd, "sc.0", x)))
     h = _ln_gelu(sd, "seg.1", _lin(sd, "seg.0", x))
     return _lin(sd, "seg.3", h)
 

@@ -57,8 +57,6 @@ class SegNetViT(blk.PackedCache, nn.Module):
         c = self.config
         if c['hidden_dim'] != 256 or c['num_heads'] != 4:
             raise NotImplementedError("HIP kernels are specialised for hidden_dim 256 / 4 heads of 64")
-        if c['with_sc']:
-            raise NotImplementedError("with_sc head is not used by any shipped config")
         self.with_cls, self.with_sc, self.with_score = c['with_cls'], c['with_sc'], c['with_score']
         self.n_layers = c['n_layers']
         self.gnn = _Stack(c['n_layers'], c['hidden_dim'])
@@ -67,12 +65,19 @@ class SegNetViT(blk.PackedCache, nn.Module):
         self.seg = nn.Sequential(nn.Linear(c['hidden_dim'], c['output_dim']),
                                  nn.LayerNorm(c['output_dim'], elementwise_affine=True), nn.GELU(),
                                  nn.Linear(c['output_dim'], c['n_class']))
+        if self.with_sc:       # second head on the same tokens (segnetvit.py:166-172,199-201); no shipped config enables it
+            self.sc = nn.Sequential(nn.Linear(c['hidden_dim'], c['output_dim']),
+                                    nn.LayerNorm(c['output_dim'], elementwise_affine=True), nn.GELU(),
+                                    nn.Linear(c['output_dim'], 3))
 
     # ---- packed device weights
     def _build_packed(self, dev):
         sd = self.state_dict()
         f = lambda k: sd[k].detach().float().contiguous().to(dev)
+        heads = ["seg"] + (["sc"] if self.with_sc else [])
+        extra = {f"{h}{i}_{n[0]}": f(f"{h}.{i}.{n}") for h in heads[1:] for i in (0, 1, 3) for n in ("weight", "bias")}
         return {
+            **extra,
             "Wr": f("kenc.Wr.weight"),
             "in_w": f("input_proj.weight"), "in_b": f("input_proj.bias"),
             "layers": [blk.pack_self_block(sd, f"gnn.layers.{i}", dev) for i in range(self.n_layers)],
@@ -107,4 +112,9 @@ class SegNetViT(blk.PackedCache, nn.Module):
         h = ops.linear(x, P["seg0_w"], P["seg0_b"])
         ops.layernorm_gelu_(h, P["seg1_w"], P["seg1_b"])
         out = ops.linear(h, P["seg3_w"], P["seg3_b"])
-        return {'prediction': out.view(B, N, -1)}
+        output = {'prediction': out.view(B, N, -1)}
+        if self.with_sc:
+            h = ops.linear(x, P["sc0_w"], P["sc0_b"])
+            ops.layernorm_gelu_(h, P["sc1_w"], P["sc1_b"])
+            output['sc'] = ops.linear(h, P["sc3_w"], P["sc3_b"]).view(B, N, 3)
+        return output

@@ -48,6 +48,19 @@ def test_segnetvit_golden(dev, golden, tag):
     assert agree > 0.999, agree
 
 
+def test_segnetvit_with_sc_head(dev, golden):
+    from pram_amd.nets.segnetvit import SegNetViT
+    g = golden("segnetvit_with_sc")
+    m = SegNetViT({"n_class": int(g["n_class"]), "n_layers": int(g["n_layers"]), "with_sc": True})
+    m.load_state_dict(W.make_state_dict("segnetvit", m.state_dict(), seed=7), strict=True)
+    m = m.to(dev).eval()
+    d0, k0 = W.synthetic_tokens(9, int(g["N"]))[:2]
+    out = m({"seg_descriptors": d0[None].to(dev), "keypoints": k0[None].to(dev), "image": torch.empty(1, 3, 480, 640)})
+    assert set(out) == {"prediction", "sc"} and tuple(out["sc"].shape) == (1, int(g["N"]), 3)
+    assert np.abs(out["sc"].cpu().numpy() - g["sc"]).max() < 1e-3
+    assert np.abs(out["prediction"][:, :8].cpu().numpy() - g["prediction_rows"]).max() < 1e-3
+
+
 def test_segnetvit_full_size_vs_oracle(dev):
     """BASELINE size (N = 2048, nc113) against the oracle."""
     desc, kp = _tokens(1, 2048)

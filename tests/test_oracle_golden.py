@@ -69,6 +69,20 @@ def test_segnetvit_golden(golden):
         assert np.abs(out[:, :8].numpy() - g["logits_rows"]).max() < XHOST
 
 
+def test_segnetvit_with_sc_golden(golden):
+    """the second head (with_sc, segnetvit.py:166-172,199-201) — recorded from the reference's module"""
+    from pram_amd.nets.segnetvit import SegNetViT
+    g = golden("segnetvit_with_sc")
+    m = SegNetViT({"n_class": int(g["n_class"]), "n_layers": int(g["n_layers"]), "with_sc": True})
+    sd = W.make_state_dict("segnetvit", m.state_dict(), seed=7)
+    m.load_state_dict(sd, strict=True)                 # same schema as the reference's with_sc model
+    d0, k0 = W.synthetic_tokens(9, int(g["N"]))[:2]
+    probes = {}
+    out = R.segnetvit_forward(sd, d0[None], k0[None], (1, 3, 480, 640), n_layers=int(g["n_layers"]), probes=probes)
+    assert np.abs(probes["sc"].numpy() - g["sc"]).max() < XHOST and tuple(probes["sc"].shape) == (1, int(g["N"]), 3)
+    assert np.abs(out[:, :8].numpy() - g["prediction_rows"]).max() < XHOST
+
+
 def test_gml_golden(golden):
     for tag, key in (("m384_n512", "image_shape"), ("m256_n256_img", "image")):
         g = golden(f"gml_{tag}")
