@@ -153,6 +153,10 @@ class ResNet4x(blk.PackedCache, nn.Module):
         lg = self._nchw_view(logits)
         return {'dense_features': desc, 'scores': score, 'logits': lg, 'semi_map': torch.softmax(lg, 1)[:, :-1]}
 
+    def extract_patches(self, batch):
+        """nets/sfd2.py:235-267 — the same dense outputs as forward()"""
+        return self.forward(batch)
+
     @torch.no_grad()
     def extract_batched(self, image: torch.Tensor, config: dict, per_image_fallback: bool = True):
         """Device-resident, sync-free form of extract_local_global for batches of independent queries:
@@ -215,6 +219,27 @@ class ResNet4x(blk.PackedCache, nn.Module):
     def sample_batched(self, score_map, mid_nhwc, kpts, counts, s=4, norm_desc=True):
         """Batched sample(): [B,k,C] token-major descriptors + [B,k] scores, no host sync."""
         return ops.score_lookup(score_map, kpts, counts), ops.sample_nhwc(mid_nhwc, kpts, counts, s, bool(norm_desc))
+
+
+class DescriptorCompressor(blk.PackedCache, nn.Module):
+    """nets/sfd2.py:372-383: Conv1d(inputdim -> outdim, kernel 1) over descriptors [B, C, N], then L2 normalisation
+    along C — a per-keypoint linear map (used by the training CLI's optional descriptor compression, main.py:51-63)."""
+
+    def __init__(self, inputdim: int, outdim: int):
+        super().__init__()
+        self.inputdim, self.outdim = inputdim, outdim
+        self.conv = nn.Conv1d(in_channels=inputdim, out_channels=outdim, kernel_size=1, padding=0, bias=True)
+
+    @torch.no_grad()
+    def forward(self, x):
+        blk.require_cuda(x, "DescriptorCompressor.forward")
+        P = self._packed_get(lambda dev: {"w": self.conv.weight.detach().float().reshape(self.outdim, self.inputdim).contiguous().to(dev),
+                                          "b": self.conv.bias.detach().float().contiguous().to(dev)})
+        b, c, n = x.shape
+        rows = x.float().transpose(1, 2).reshape(b * n, c)
+        y = ops.linear(rows, P["w"], P["b"])
+        ops.l2norm_rows_(y)
+        return y.view(b, n, self.outdim).transpose(1, 2)
 
 
 def load_sfd2(weight_path):

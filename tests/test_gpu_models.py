@@ -61,6 +61,26 @@ def test_segnetvit_with_sc_head(dev, golden):
     assert np.abs(out["prediction"][:, :8].cpu().numpy() - g["prediction_rows"]).max() < 1e-3
 
 
+def test_descriptor_compressor_and_extract_patches(dev):
+    """DescriptorCompressor (nets/sfd2.py:372-383) against the same two torch ops on the CPU; extract_patches == forward."""
+    from pram_amd.nets.sfd2 import DescriptorCompressor, ResNet4x
+    m = DescriptorCompressor(128, 64)
+    with torch.no_grad():
+        m.conv.weight.copy_(W.normal(3, "dc/w", (64, 128, 1), 0.1))
+        m.conv.bias.copy_(W.normal(3, "dc/b", (64,), 0.1))
+    x = W.normal(3, "dc/x", (2, 128, 300), 1.0)
+    ref = torch.nn.functional.normalize(torch.nn.functional.conv1d(x, m.conv.weight, m.conv.bias), p=2, dim=1)
+    out = m.to(dev)(x.to(dev))
+    assert tuple(out.shape) == (2, 64, 300) and H.maxdiff(out, ref) < 1e-5
+    net = ResNet4x()
+    net.load_state_dict(H.sfd2_sd(), strict=True)
+    net = net.to(dev).eval()
+    img = W.synthetic_image(2, 64, 96)[None].to(dev)
+    a, b = net.forward({"image": img}), net.extract_patches({"image": img})
+    assert set(a) == set(b) == {"dense_features", "scores", "logits", "semi_map"}
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
 def test_segnetvit_full_size_vs_oracle(dev):
     """BASELINE size (N = 2048, nc113) against the oracle."""
     desc, kp = _tokens(1, 2048)
