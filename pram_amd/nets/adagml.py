@@ -100,6 +100,21 @@ class AdaGML(GML):
         """nets/adagml.py:516-520"""
         return float(np.clip(0.5 + 0.1 * np.exp(-4.0 * layer_index / self.n_layers), 0, 1))
 
+    # API parity helpers (nets/adagml.py:491-514,522-538); produce_matches applies the same rules inside its kernels
+    def compute_score(self, dist, dustbin, iteration):
+        return GML.compute_score(self, dist, dustbin, iteration)
+
+    def compute_matches(self, scores, p=0.2):
+        return GML.compute_matches(self, scores, p)
+
+    def check_if_stop(self, confidences0: torch.Tensor, confidences1: torch.Tensor, layer_index: int, num_points: int) -> torch.Tensor:
+        confidences = torch.cat([confidences0, confidences1], -1)
+        pos = 1.0 - (confidences < self.confidence_threshold(layer_index)).float().sum() / num_points
+        return pos > 0.95
+
+    def stop_iteration(self, m_last, n_last, m_current, n_current, confidence=0.975):
+        return (m_current + n_current) / (m_last + n_last) > confidence
+
     def _pool_logit(self, pp, x, score4):
         """PoolingLayer.forward up to the pre-sigmoid logit (nets/adagml.py:132-136)."""
         s = ops.linear(score4, pp["se0_w"], pp["se0_b"])

@@ -18,3 +18,8 @@ def normalize_keypoints(kpts: torch.Tensor, image_shape) -> torch.Tensor:
     """Tensor form with the reference's arithmetic (subtract centre, divide by 0.7 * longer side)."""
     cx, cy, scale = keypoint_norm_constants(image_shape)
     return (kpts - kpts.new_tensor([cx, cy])) / kpts.new_tensor(scale)
+
+
+def arange_like(x: torch.Tensor, dim: int) -> torch.Tensor:
+    """0 .. x.shape[dim]-1 in x's dtype and device (nets/utils.py:13)."""
+    return torch.arange(x.shape[dim], device=x.device, dtype=x.dtype)

@@ -81,6 +81,29 @@ def test_descriptor_compressor_and_extract_patches(dev):
     assert all(torch.equal(a[k], b[k]) for k in a)
 
 
+def test_adagml_parity_helpers(dev):
+    """compute_score / compute_matches / check_if_stop / stop_iteration / arange_like — small public helpers of
+    nets/adagml.py:491-538 and nets/utils.py:13, against the oracle's restatement of the same lines."""
+    from pram_amd.nets.adagml import AdaGML
+    from pram_amd.nets.utils import arange_like
+    net = AdaGML({}).to(dev).eval()
+    M = W.normal(14, "helpers/M", (2, 40, 55), 2.0)
+    bin_score = torch.tensor(1.0)
+    want = R.sink_algorithm(M, bin_score, 20)
+    got = net.compute_score(M.to(dev), bin_score.to(dev), 20)
+    assert H.maxdiff(got, want) < 1e-5
+    i0, i1, s0, s1 = net.compute_matches(got, p=0.1)
+    w0, w1, ws0, ws1 = R.compute_matches(want, 0.1)
+    assert torch.equal(i0.cpu(), w0) and torch.equal(i1.cpu(), w1) and H.maxdiff(s0, ws0) < 1e-5 and H.maxdiff(s1, ws1) < 1e-5
+    c0, c1 = torch.linspace(0, 1, 50, device=dev), torch.linspace(0.4, 1, 70, device=dev)
+    for layer in (0, 4, 8):
+        thr = R.adagml_confidence_threshold(layer)
+        want_stop = 1.0 - float(((torch.cat([c0, c1]) < thr).float().sum() / 120).cpu()) > 0.95
+        assert bool(net.check_if_stop(c0, c1, layer, 120)) == want_stop
+    assert net.stop_iteration(100, 100, 196, 0) and not net.stop_iteration(100, 100, 150, 40)
+    assert torch.equal(arange_like(torch.zeros(3, 7, device=dev, dtype=torch.int64), 1).cpu(), torch.arange(7))
+
+
 def test_segnetvit_full_size_vs_oracle(dev):
     """BASELINE size (N = 2048, nc113) against the oracle."""
     desc, kp = _tokens(1, 2048)
