@@ -119,3 +119,12 @@ def test_config_values_of_7scenes(golden):
     m = load_segnet(cfg["network"], cfg["n_class"], 256 if cfg["use_mid_feature"] else 128, cfg["layers"], cfg["output_dim"])
     assert m.config["n_class"] == 113 and m.n_layers == 15 and m.config["output_dim"] == 1024
     assert cfg["localization"]["matching_method"] == "gml"
+
+
+def test_gm_module_mirrors_the_reference_state():
+    """nets/gm.py: the class is unconstructible in the reference and says so here; its free functions are GML's."""
+    import pytest
+    from pram_amd.nets import gm, gml
+    assert gm.sink_algorithm is gml.sink_algorithm and gm.dual_softmax is gml.dual_softmax
+    with pytest.raises(TypeError, match="cannot be constructed"):
+        gm.GM({})
