@@ -62,6 +62,13 @@ int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int 
                         float* out, int ldo, int m, int n, float alpha, int flags,
                         const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
 
+/* pram_linear_f16_f32 that also (or only: out may be NULL) writes the result rounded to fp16 — the q / k / v operand
+ * of pram_attention_h16_f32, which would otherwise round the fp32 result itself while staging it (same values). */
+int pram_linear_f16_h16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                        const void* w16, const float* bias, const float* residual, int ldr,
+                        float* out, int ldo, void* out16, int ldo16, int m, int n, float alpha, int flags,
+                        const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
+
 /* Batched C_b = alpha * A_b · B_bᵀ (einsum 'bmd,bnd->bmn', nets/gml.py:282; K12).
  * A_b = a + b*stride_a, [m_max][lda]; B_b [n_max][ldb]; C_b [m_max][ldc]. */
 int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
@@ -104,6 +111,13 @@ size_t pram_attention_workspace_bytes(int batch, int heads, int m_max, int n_max
 int pram_attention_f16_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            float* out, int ldo, float* lse2, const int* q_lens, const int* k_lens,
                            int batch, int heads, int m_max, int n_max, float scale, void* stream);
+
+/* pram_attention_f16_f32 on q / k / v that are already fp16 in HBM (ld* in halves, multiples of 8): bit-identical
+ * output, half the operand traffic, two K/V tiles in flight.  kv_shift = 0 for self attention; = pairs with
+ * batch = 2*pairs for the single-launch cross attention (see pram_attention_cross_f32). */
+int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, const void* v16, int ldv, float* out,
+                           int ldo, float* lse2, const int* q_lens, const int* k_lens, int batch, int heads,
+                           int m_max, int n_max, float scale, int kv_shift, void* stream);
 
 /* Both directions of CrossMultiHeadAttention.forward (nets/gml.py:175-179; adagml.py:222-231) in ONE launch:
  * 2*pairs sequences of t_max rows each, sequences 0..pairs-1 = set 0, pairs..2*pairs-1 = set 1; sequence s takes

@@ -21,11 +21,13 @@ _SIGS = {
     "pram_last_error": (C.c_char_p, []),
     "pram_linear_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_f16_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
+    "pram_linear_f16_h16": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_bgemm_nt_f32": (I, [P, I, LL, P, I, LL, P, I, LL, I, I, I, I, F, P]),
     "pram_layernorm_gelu_f32": (I, [P, I, P, I, P, P, I, I, F, P]),
     "pram_fourier_encoding_f32": (I, [P, P, F, F, F, P, P, I, P]),
     "pram_attention_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P, SZ, P]),
     "pram_attention_workspace_bytes": (SZ, [I, I, I, I]),
+    "pram_attention_h16_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_f16_f32": (I, [P, I, P, I, P, I, P, I, P, P, P, I, I, I, I, F, P]),
     "pram_attention_colmean_f32": (I, [P, I, P, I, P, P, P, P, I, I, I, I, F, P]),
     "pram_attention_cross_f32": (I, [P, I, P, I, P, I, P, P, I, I, I, F, P, SZ, P]),

@@ -212,6 +212,181 @@ __global__ __launch_bounds__(256, 3) void attention_f16_kernel(Args p) {
     }
 }
 
+
+// ---------------------------------------------------------------- fp16 inputs in HBM
+// Same arithmetic as attention_f16_kernel — it rounds Q / K / V to fp16 while staging them; here the producing GEMM
+// has already written exactly those fp16 values (pram_linear_f16_h16), so the outputs are bit-identical — but half
+// the bytes cross L2 -> LDS, the staging needs no conversion and half the registers, and that buys the thing this
+// kernel is actually short of: with 512 matrix cycles per tile, one K/V tile in flight leaves the loop waiting on a
+// global-load round trip per tile.  Tile t+2 is requested while tile t is multiplied (two register sets, tile c in
+// set c & 1; the LDS stage stays double buffered).
+struct ArgsH {
+    const _Float16* q; const _Float16* k; const _Float16* v;
+    float* out; float* lse2;
+    const int* q_lens; const int* k_lens;
+    int ldq, ldk, ldv, ldo;          // ldq / ldk / ldv in halves
+    int batch, heads, m_max, n_max;
+    float scale2;
+    int q_tiles;
+    int kv_shift;
+};
+
+__global__ __launch_bounds__(256, 3) void attention_h16_kernel(ArgsH p) {
+    __shared__ Smem s;
+    const int nblk = p.batch * p.heads * p.q_tiles;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int qt = id % p.q_tiles;
+    const int bh = id / p.q_tiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
+    if (qt * BQ >= qlen || klen <= 0) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qt * BQ + wave * QW;
+    const bool wave_active = q0 < qlen;
+    const int qrow = q0 + r;
+    const bool q_ok = qrow < qlen;
+
+    const _Float16* qp = p.q + ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
+    const _Float16* kp = p.k + (size_t)kb * p.n_max * p.ldk + head * D;
+    const _Float16* vp = p.v + (size_t)kb * p.n_max * p.ldv + head * D;
+
+    half8 qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qf[c] = *reinterpret_cast<const half8*>(qp + c * 16 + h * 8);
+        if (!q_ok)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[c][i] = (_Float16)0.f;
+    }
+
+    const int lrow = tid >> 3, lseg = tid & 7;      // staging: key lrow + 32p, halves 8*lseg .. 8*lseg+7
+    auto gload = [&](int kt, half8 (&kr)[2], half8 (&vr)[2]) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int kc = min(kt * BKV + lrow + 32 * pp, klen - 1);
+            kr[pp] = *reinterpret_cast<const half8*>(kp + (size_t)kc * p.ldk + lseg * 8);
+            vr[pp] = *reinterpret_cast<const half8*>(vp + (size_t)kc * p.ldv + lseg * 8);
+        }
+    };
+    auto lstore = [&](int buf, int kt, const half8 (&kr)[2], const half8 (&vr)[2]) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row = lrow + 32 * pp;
+            const bool ok = kt * BKV + row < klen;
+            half8 kv = kr[pp], vv = vr[pp];
+            if (!ok)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { kv[i] = (_Float16)0.f; vv[i] = (_Float16)0.f; }
+            *reinterpret_cast<half8*>(&s.k[buf][row * D + ((lseg ^ ((row >> 1) & 7)) << 3)]) = kv;
+            const int pos = pos_of_key(row);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = lseg * 8 + j;
+                const int vslot = (pos >> 3) ^ ((d >> 1) & 7);
+                s.vt[buf][d * BKV + vslot * 8 + (pos & 7)] = vv[j];
+            }
+        }
+    };
+
+    const int nkt = (klen + BKV - 1) / BKV;
+    half8 kA[2], vA[2], kB[2], vB[2];
+    gload(0, kA, vA);
+    if (nkt > 1) gload(1, kB, vB);
+    lstore(0, 0, kA, vA);
+    __syncthreads();
+
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+
+    auto tile = [&](int kt, half8 (&kn)[2], half8 (&vn)[2], const half8 (&kc)[2], const half8 (&vc)[2]) {
+        const int cur = kt & 1;
+        if (kt + 2 < nkt) gload(kt + 2, kn, vn);       // into the set tile kt has left
+        if (wave_active) {
+            f32x16 st[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
+            const _Float16* sk = s.k[cur];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = (2 * c + h) ^ ((r >> 1) & 7);
+                const half8 k0 = *reinterpret_cast<const half8*>(sk + r * D + slot * 8);
+                const half8 k1 = *reinterpret_cast<const half8*>(sk + (32 + r) * D + slot * 8);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[c], st[1], 0, 0, 0);
+            }
+            if (kt + 1 == nkt && (klen & (BKV - 1))) {
+                const int kbase = kt * BKV;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + t * 32 + key_of(e, h) >= klen) st[t][e] = -INFINITY;
+            }
+            float tmax = st[0][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax * p.scale2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.f;
+            half8 pf[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, -m_new));
+                    psum += pv;
+                    pf[t][e >> 3][e & 7] = (_Float16)pv;
+                }
+            l_run = fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+            const _Float16* sv = s.vt[cur];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int slot = t * 4 + u * 2 + h;
+                    const half8 v0 = *reinterpret_cast<const half8*>(sv + r * BKV + ((slot ^ ((r >> 1) & 7)) << 3));
+                    const half8 v1 = *reinterpret_cast<const half8*>(sv + (32 + r) * BKV + ((slot ^ ((r >> 1) & 7)) << 3));
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[t][u], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[t][u], oacc[1], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nkt) lstore(cur ^ 1, kt + 1, kc, vc);   // tile kt+1, requested one iteration ago
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, kA, vA, kB, vB);
+        if (kt + 1 < nkt) tile(kt + 1, kB, vB, kA, vA);
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
+                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
+            }
+        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + log2f(l_tot);
+    }
+}
+
 }  // namespace
 
 extern "C" int pram_attention_f16_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
@@ -236,4 +411,20 @@ extern "C" int pram_attention_cross_f16_f32(const float* qk, int ldqk, const flo
     Args p{qk, qk, v, out, lse2, lens, lens, ldqk, ldqk, ldv, ldo, 2 * pairs, heads, t_max, t_max, scale * LOG2E, cdiv(t_max, BQ), pairs};
     hipLaunchKernelGGL(attention_f16_kernel, dim3(2 * pairs * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_cross_f16_f32");
+}
+
+
+/* fp16 q / k / v in HBM (written by pram_linear_f16_h16): ld* in halves, 16-byte aligned rows and head offsets. */
+extern "C" int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, const void* v16, int ldv, float* out,
+                                      int ldo, float* lse2, const int* q_lens, const int* k_lens, int batch, int heads,
+                                      int m_max, int n_max, float scale, int kv_shift, void* stream) {
+    PRAM_REQUIRE(q16 && k16 && v16 && out, "pram_attention_h16_f32: null pointer");
+    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "pram_attention_h16_f32: ld of the fp16 operands must be a multiple of 8");
+    PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_h16_f32: bad sizes");
+    if (batch == 0 || m_max == 0) return PRAM_OK;
+    PRAM_REQUIRE(n_max > 0, "pram_attention_h16_f32: empty key set");
+    ArgsH p{(const _Float16*)q16, (const _Float16*)k16, (const _Float16*)v16, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo,
+            batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift};
+    hipLaunchKernelGGL(attention_h16_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_h16_f32");
 }

@@ -20,6 +20,9 @@ struct LinArgs {
     // batching (bgemm): per-z strides in floats; 0 for plain linear
     long long sa, sw, so;
     int tiles_m, tiles_n;
+    // optional fp16 copy of the output (same values, rounded to nearest even) for the fp16 attention kernel, which
+    // would otherwise round the fp32 output itself while staging it; `out` may be null when only the copy is wanted
+    void* out16; int ldo16;
 };
 
 // Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
@@ -74,6 +77,18 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             q0[e] = v0;
             q1[e] = v1;
         }
+        if (p.out16) {
+            _Float16* o16 = reinterpret_cast<_Float16*>(p.out16);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + acc_row(mi, e, h);
+                if (row < p.m) {
+                    if (c0ok) o16[(size_t)row * p.ldo16 + c0] = (_Float16)q0[e];
+                    if (c1ok) o16[(size_t)row * p.ldo16 + c1] = (_Float16)q1[e];
+                }
+            }
+        }
+        if (out == nullptr) continue;
         if (full) {   // block-uniform fast path: no per-element predicates
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -280,6 +295,28 @@ extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const floa
     if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
     else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
     return pram_launch_status("pram_linear_f16_f32");
+}
+
+extern "C" int pram_linear_f16_h16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
+                                   const float* bias, const float* residual, int ldr, float* out, int ldo, void* out16,
+                                   int ldo16, int m, int n, float alpha, int flags, const float* rot_cos,
+                                   const float* rot_sin, int rot_cols, void* stream) {
+    PRAM_REQUIRE(a0 && w16 && out16, "pram_linear_f16_h16: null pointer");
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "pram_linear_f16_h16: bad sizes");
+    PRAM_REQUIRE((k0 + k1) % 8 == 0 && lda0 % 4 == 0, "pram_linear_f16_h16: K must be a multiple of 8, lda of 4");
+    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemm16::BK == 0 && lda1 % 4 == 0), "pram_linear_f16_h16: concat needs k0 %% 64 == 0");
+    if (flags & PRAM_LIN_ROTARY)
+        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_f16_h16: rotary needs cos/sin and rot_cols %% 64 == 0");
+    if (m == 0) return PRAM_OK;
+    LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out16, ldo16};
+    int mi, wn;
+    gemm::choose_tile(m, n, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* w = (const _Float16*)w16;
+    if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
+    else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
+    return pram_launch_status("pram_linear_f16_h16");
 }
 
 extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,

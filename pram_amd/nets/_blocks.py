@@ -73,6 +73,11 @@ def pack_cross_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[s
     return {k: v.contiguous().to(device) for k, v in out.items()}
 
 
+def _half_path() -> bool:
+    """both the token GEMMs and the attention run on the fp16 MFMA path (BASELINE C5): q / k / v can travel as fp16"""
+    return ops.gemm_precision == "f16" and ops.attention_precision == "f16"
+
+
 def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
     """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0"""
     h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx)
@@ -83,10 +88,15 @@ def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor]) ->
 def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, sin: torch.Tensor, S: int, T: int,
                lens: Optional[torch.Tensor], want_colmean: bool = False):
     """x [S*T, 256] -> same.  SelfMultiHeadAttention.forward (nets/segnetvit.py:97-106)."""
-    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH))
     hid = HEADS * DH
-    q, k, v = qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:]
     scale = DH ** -0.5
+    if _half_path() and not want_colmean:
+        # fp16 path: the projection writes q | k | v as fp16 only (what the fp16 attention would round them to anyway)
+        _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), half_copy="only")
+        ctx = ops.attention_h16(h16[:, :hid], h16[:, hid:2 * hid], h16[:, 2 * hid:], S, HEADS, T, T, scale, lens, lens)
+        return _mlp_tail(x, ctx, p)
+    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH))
+    q, k, v = qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:]
     if want_colmean:
         ctx, lse = ops.attention(q, k, v, S, HEADS, T, T, scale, lens, lens, want_lse=True)
         col = ops.attention_colmean(q, k, lse, S, HEADS, T, T, scale, lens, lens)
@@ -100,9 +110,14 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     """x [2B*T, 256]: sequences 0..B-1 are set 0, B..2B-1 set 1.  CrossMultiHeadAttention.forward
     (nets/gml.py:164-186): m0 = softmax_row(sim) v1, m1 = softmax_row(sim^T) v0."""
     hid = HEADS * DH
+    scale = DH ** -0.5     # (dh^-1/4)^2
+    if _half_path() and not want_colmean:
+        _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], half_copy="only")
+        qk16, v16 = h16[:, :hid], h16[:, hid:]
+        ctx = ops.attention_h16(qk16, qk16, v16, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
+        return _mlp_tail(x, ctx, p)
     qkv = ops.linear(x, p["qkv_w"], p["qkv_b"])          # [2B*T, 512] = [qk | v]
     qk, v = qkv[:, :hid], qkv[:, hid:]
-    scale = DH ** -0.5     # (dh^-1/4)^2
     # one launch for both directions: sequence s attends to sequence (s + B) mod 2B
     if want_colmean:
         ctx, lse = ops.attention_cross(qk, v, B, HEADS, T, scale, lens, want_lse=True)

@@ -37,8 +37,10 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-           rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> torch.Tensor:
-    """out = alpha * ([x | x2] @ w.T + bias) + residual.  x [..., k0] (contiguous rows), w [n, k0+k1]."""
+           rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, half_copy: str = "no"):
+    """out = alpha * ([x | x2] @ w.T + bias) + residual.  x [..., k0] (contiguous rows), w [n, k0+k1].
+    half_copy (fp16 GEMM path only): "also" -> returns (out fp32, out fp16), "only" -> returns (None, out fp16): the
+    fp16 operand of attention_h16."""
     L = _lib.load()
     x = x.contiguous()
     m, k0 = _rows2d(x, "x")
@@ -62,6 +64,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         rc, rs, rcols = rotary
         flags = 1
     use16 = gemm_precision == "f16" and (k0 + k1) % 64 == 0 and (k1 == 0 or k0 % 64 == 0)
+    if half_copy != "no":
+        if not use16:
+            raise _lib.PramHipError("linear(half_copy=...) needs the fp16 GEMM path (gemm_precision == 'f16', K % 64 == 0)")
+        out16 = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float16)
+        o32 = out if half_copy == "also" else None
+        _lib.check(L.pram_linear_f16_h16(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual), n, _p(o32), n,
+                                         _p(out16), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+                   "pram_linear_f16_h16")
+        return o32, out16
     if use16:
         _lib.check(L.pram_linear_f16_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual),
                                          n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
@@ -185,6 +196,31 @@ def attention_colmean(q: torch.Tensor, k: torch.Tensor, lse2: torch.Tensor, batc
                                             _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
                "pram_attention_colmean_f32")
     return out
+
+
+def attention_h16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int, scale: float,
+                  q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None, want_lse: bool = False,
+                  out: Optional[torch.Tensor] = None, kv_shift: int = 0):
+    """attention(precision="f16") on fp16 q / k / v (2-D views, possibly column slices of one fp16 projection output):
+    same bits out, half the operand traffic.  kv_shift: see attention_cross."""
+    L = _lib.load()
+    for t in (q, k, v):
+        assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
+    if out is None:
+        out = torch.empty(batch * m_max, heads * 64, device=q.device, dtype=torch.float32)
+    lse = torch.empty(batch, heads, m_max, device=q.device, dtype=torch.float32) if want_lse else None
+    probe = attention_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(L.pram_attention_h16_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                        _p(lse), _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift),
+                                        _st()), "pram_attention_h16_f32")
+    if probe is not None:
+        e1.record()
+        kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
+        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1))
+    return (out, lse) if want_lse else out
 
 
 def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t_max: int, scale: float,

@@ -263,6 +263,40 @@ def test_attention_cross_equals_two_calls(dev, prec):
     assert torch.equal(o2[:half], o20)
 
 
+def test_fp16_operands_in_hbm_equal_the_staged_rounding(dev):
+    """C5 path: the projection can hand q / k / v over as fp16 (pram_linear_f16_h16) and attention_h16 reads them
+    directly.  Both steps only move WHERE the round-to-fp16 happens, so: the fp16 copy equals the fp32 output rounded,
+    and attention_h16 equals attention(precision="f16") on the fp32 tensors — bit for bit, self and cross, ragged."""
+    from pram_amd import ops
+    Hh, T, S = 4, 333, 4
+    x = rnd(9, "h16/x", (S * T, 256)).to(dev)
+    w, b = rnd(9, "h16/w", (768, 256), 0.06).to(dev), rnd(9, "h16/b", (768,), 0.1).to(dev)
+    old = ops.gemm_precision
+    try:
+        ops.gemm_precision = "f16"
+        o32 = ops.linear(x, w, b)
+        o32b, o16 = ops.linear(x, w, b, half_copy="also")
+        _, o16only = ops.linear(x, w, b, half_copy="only")
+    finally:
+        ops.gemm_precision = old
+    assert torch.equal(o32, o32b) and torch.equal(o16, o32.half()) and torch.equal(o16only, o16)
+    lens = torch.tensor([333, 200, 64, 301], dtype=torch.int32, device=dev)
+    q, k, v = o32[:, :256], o32[:, 256:512], o32[:, 512:]
+    ref, lse = ops.attention(q, k, v, S, Hh, T, T, 0.125, lens, lens, want_lse=True, precision="f16")
+    got, lse2 = ops.attention_h16(o16[:, :256], o16[:, 256:512], o16[:, 512:], S, Hh, T, T, 0.125, lens, lens, want_lse=True)
+    for s_ in range(S):
+        n = int(lens[s_])
+        assert torch.equal(got.view(S, T, 256)[s_, :n], ref.view(S, T, 256)[s_, :n]) and torch.equal(lse2[s_, :, :n], lse[s_, :, :n])
+    # cross pairing (kv_shift) against the fp32-input single-launch cross attention on the fp16 MFMA path
+    refx = ops.attention_cross(q, v, S // 2, Hh, T, 0.125, lens, precision="f16")
+    gotx = ops.attention_h16(o16[:, :256], o16[:, :256], o16[:, 512:], S, Hh, T, T, 0.125, lens, lens, kv_shift=S // 2)
+    for s_ in range(S):
+        n = int(lens[s_])
+        assert torch.equal(gotx.view(S, T, 256)[s_, :n], refx.view(S, T, 256)[s_, :n])
+    with pytest.raises(Exception):
+        ops.linear(x, w, b, half_copy="only")          # needs the fp16 GEMM path
+
+
 # ------------------------------------------------------------------ sinkhorn / matches
 def _sink_input(tag, m, n):
     M = W.normal(11, f"sink/{tag}", (2, m, n), 2.0)
