@@ -30,29 +30,21 @@ for ov in (0, 8):
     t2 = time.perf_counter()
     print(f"B={B} overlap_below={ov}: host enqueue {1e3*(t1-t0)/10:.2f} ms/step, total {1e3*(t2-t0)/10:.2f} ms/step")
 
-# graph capture
+# graph capture (the product's wrapper)
+from pram_amd.pipeline import GraphedPipeline
 pipe.overlap_below = 8
-g = torch.cuda.CUDAGraph()
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(2):
-        pipe.run(images, ref)
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
 try:
-    with torch.cuda.graph(g):
-        gout = pipe.run(images, ref)
-    torch.cuda.synchronize()
+    gp = GraphedPipeline(pipe, images, ref)
     for _ in range(3):
-        g.replay()
+        gp.run(images, ref)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(10):
-        g.replay()
-    torch.cuda.synchronize()
+        gout = gp.run(images, ref)
     t1 = time.perf_counter()
-    print(f"B={B} graph replay: {1e3*(t1-t0)/10:.2f} ms/step")
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"B={B} hipGraph replay: host {1e3*(t1-t0)/10:.2f} ms/step, total {1e3*(t2-t0)/10:.2f} ms/step")
     ok = torch.equal(gout["matches0"], out["matches0"]) and torch.equal(gout["prediction"], out["prediction"])
     print("graph == eager:", ok)
 except Exception as e:

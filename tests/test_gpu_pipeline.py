@@ -94,3 +94,22 @@ def test_batches_in_flight_on_separate_streams_equal_serial(dev):
         torch.cuda.synchronize()
         for a, b in zip(got, serial):
             assert torch.equal(a, b)
+
+
+def test_graphed_pipeline_equals_eager(dev):
+    """the whole step captured as a hipGraph (no host synchronisation inside) and replayed on new inputs == eager run"""
+    from pram_amd.pipeline import GraphedPipeline, QueryPipeline
+    sfd2, seg, gml = _models(dev)
+    pipe = QueryPipeline(sfd2, seg, gml, max_keypoints=192, min_keypoints=8)
+    mk = lambda j: torch.stack([W.synthetic_image(20 * j + i, 96, 128) for i in range(2)]).to(dev)
+    imgs = [mk(0), mk(1), mk(2)]
+    ex = sfd2.extract_batched(imgs[0], pipe.cfg)
+    ref = {"descriptors": ex["descriptors"].flip(1).contiguous(), "keypoints": ex["keypoints"].flip(1).contiguous(),
+           "scores": ex["scores"].flip(1).contiguous()}
+    g = GraphedPipeline(pipe, imgs[0], ref)
+    for img in imgs[1:] + imgs[:1]:
+        want = QueryPipeline.pack_record(pipe.run(img, ref)).clone()
+        got = QueryPipeline.pack_record(g.run(img, ref))
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        g.run(imgs[0][:1], ref)
