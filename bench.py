@@ -3,18 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of 16 synthetic query frames per GPU
-(SFD2 extract + sample -> SegNetViT nc113 -> GML match with 20 Sinkhorn iterations against a
-2048-keypoint reference set), inputs resident in HBM.  Queries shard across ranks with no data-path
-collective; each step ends with the single all-gather of the fixed-size result records.
-Prints ONE JSON line on rank 0 (contract in the task statement): metric / value (whole-job
-queries/s) / roofline (attention kernel, f32 MFMA) / cpu_baseline (oracle on the host cores).
+A "step" is one pass of the hot path over one batch of synthetic query frames (16 per GPU by default =
+BASELINE configs[1]; ``--batch-total Q`` shards Q queries over the N ranks instead = configs[2] / [4]):
+SFD2 extract + sample -> SegNetViT nc113 -> GML match with 20 Sinkhorn iterations against a 2048-keypoint
+reference set, inputs resident in HBM.  Queries shard across ranks with no data-path collective; each step ends
+with the single all-gather of the fixed-size result records.
+
+With ``--gpus N`` (N > 1) and no launcher in the environment the script starts its own N ranks
+(``torch.distributed.run``, one process per GPU over RCCL) and refuses to run when fewer than N GPUs are visible.
+
+Rank 0 prints ONE JSON line (contract in the task statement): metric / value (whole-job queries/s) / roofline
+(attention kernel) / parity (one untimed query checked against the oracle, stage by stage) / cpu_baseline (the
+oracle on the host cores, per stage, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -25,11 +33,13 @@ if str(ROOT) not in sys.path:
 
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+# MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz; dense f16 MFMA ~2.5 PFLOP/s
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
 H, W_IMG = 480, 640
 
 
-def build_models(dev, matcher_name, n_class=113):
+def build_models(dev, matcher_name, n_class=113, precision=None):
     from pram_amd import weights as W
     from pram_amd.nets.adagml import AdaGML
     from pram_amd.nets.gml import GML
@@ -45,27 +55,39 @@ def build_models(dev, matcher_name, n_class=113):
     return sfd2, seg, matcher, sds
 
 
-def make_reference_sets(q_desc, q_kpts, q_scores, seed_base):
-    """ref set = permuted copy of the query descriptors + 0.2 N(0,1)/sqrt(128) noise,
-    re-normalised, last 25 % replaced by random unit vectors.  Built once, untimed."""
+def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise=0.05):
+    """the reference set of a query = a permuted copy of its descriptors + noise, re-normalised, the
+    last 25 % replaced by outliers (fresh keypoint positions, descriptors drawn around the population mean).  The noise
+    and the outliers are scaled to the DISCRIMINATIVE part of the descriptors (||d - mean|| ~ 0.18 on the synthetic
+    SFD2 weights), not to their unit norm.  Built once, untimed.  Returns (ref, gt) with gt[b, i] = index of query
+    keypoint i's twin in the reference set or -1."""
     from pram_amd import weights as W
     B, k, D = q_desc.shape
     dev = q_desc.device
-    descs, kps, scs = [], [], []
+    mu = q_desc.reshape(-1, D).mean(0)
+    spread = float((q_desc.reshape(-1, D) - mu).norm(dim=1).mean())
+    descs, kps, scs, gts = [], [], [], []
     for b in range(B):
         seed = seed_base + b
         perm = torch.argsort(W.uniform(seed, "bench/perm", (k,), 0.0, 1.0)).to(dev)
-        d = q_desc[b, perm] + W.normal(seed, "bench/noise", (k, D), 0.2 / D ** 0.5).to(dev)
+        d = q_desc[b, perm] + W.normal(seed, "bench/noise", (k, D), noise * spread / D ** 0.5 * 5.0).to(dev)
         kp = q_kpts[b, perm].clone()
         n_out = k // 4
-        d[k - n_out:] = W.normal(seed, "bench/out", (n_out, D), 1.0).to(dev)
+        d[k - n_out:] = mu + W.normal(seed, "bench/out", (n_out, D), spread / D ** 0.5).to(dev)
         kp[k - n_out:, 0] = torch.floor(W.uniform(seed, "bench/ox", (n_out,), 4.0, W_IMG - 4.0)).to(dev)
         kp[k - n_out:, 1] = torch.floor(W.uniform(seed, "bench/oy", (n_out,), 4.0, H - 4.0)).to(dev)
         descs.append(torch.nn.functional.normalize(d, dim=-1))
         kps.append(kp)
         scs.append(W.uniform(seed, "bench/sc", (k,), 0.0, 1.0).to(dev))
-    return {"descriptors": torch.stack(descs).contiguous(), "keypoints": torch.stack(kps).contiguous(),
-            "scores": torch.stack(scs).contiguous()}
+        gt = torch.full((k,), -1, dtype=torch.long, device=dev)
+        inl = torch.arange(k - n_out, device=dev)
+        src = perm[:k - n_out]
+        ok = src < counts[b]                       # padded query rows have no twin
+        gt[src[ok]] = inl[ok]
+        gts.append(gt)
+    ref = {"descriptors": torch.stack(descs).contiguous(), "keypoints": torch.stack(kps).contiguous(),
+           "scores": torch.stack(scs).contiguous()}
+    return ref, torch.stack(gts)
 
 
 def usable_cores() -> int:
@@ -91,8 +113,64 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(sds, matcher_name, n_queries, kpts, budget_s=40.0):
-    """The oracle (CPU restatement pinned to the reference) on the host cores, same synthetic workload."""
+def _oracle_matcher(name):
+    from oracle import ref_cpu as R
+    return R.gml_produce_matches if name == "gml" else R.adagml_produce_matches
+
+
+def parity_gate(pipe, sds, matcher_name, images, ref, kpts):
+    """One untimed query through the HIP path, checked stage by stage against the oracle (CPU restatement pinned to the
+    reference): the extraction against the oracle's own extraction of the same frame; the recogniser and the matcher
+    stage-isolated (the oracle is fed the HIP path's keypoints / descriptors, so one flipped near-tie in the keypoint
+    order cannot cascade into a spurious mismatch).  Bars: fp32 outputs 1e-3, indices exact (north_star)."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(usable_cores())
+    img = images[:1]
+    ref1 = None if ref is None else {k: v[:1] for k, v in ref.items()}
+    with torch.no_grad():
+        out = pipe.run(img, ref1, stages="erm" if ref1 is not None else "er")
+        torch.cuda.synchronize()
+        n = int(out["counts"][0].item())
+        kp = out["keypoints"][0, :n].cpu()
+        o = R.sfd2_extract_local_global(sds["sfd2"], img.cpu(), max_keypoints=kpts, min_keypoints=128, per_image_fallback=True)
+        okp = o["keypoints"][0]
+        same_set = {(int(x), int(y)) for x, y in kp.tolist()} == {(int(x), int(y)) for x, y in okp.tolist()}
+        same_pos = float((kp[:min(n, len(okp))] == okp[:min(n, len(okp))]).all(1).float().mean()) if n else 1.0
+        res = {"extract": {"keypoints": n, "keypoint_set_identical": bool(same_set and n == len(okp)),
+                           "keypoints_same_position_frac": round(same_pos, 5)}}
+        ok = res["extract"]["keypoint_set_identical"]
+        # recogniser, stage-isolated
+        _, segd = R.sfd2_sample(o["score_map"], o["mid_features"], kp, norm_desc=False)
+        ref_logits = R.segnetvit_forward(sds["segnetvit"], segd.t()[None], kp[None], tuple(img.shape))[0]
+        got = out["prediction"][0, :n].cpu()
+        d_log = float((got - ref_logits).abs().max())
+        agree = float((got.argmax(-1) == ref_logits.argmax(-1)).float().mean())
+        res["recognise"] = {"logits_maxdiff": float(f"{d_log:.3e}"), "argmax_agreement": round(agree, 6)}
+        ok = ok and d_log < 1e-3 and agree == 1.0
+        if ref1 is not None:
+            data = {"descriptors0": out["descriptors"][:1, :n].cpu(), "keypoints0": kp[None], "scores0": out["scores"][:1, :n].cpu(),
+                    "descriptors1": ref1["descriptors"].cpu(), "keypoints1": ref1["keypoints"].cpu(), "scores1": ref1["scores"].cpu(),
+                    "image_shape0": (1, 3, W_IMG, H), "image_shape1": (1, 3, W_IMG, H)}
+            r = _oracle_matcher(matcher_name)(sds[matcher_name], data)
+            m_got, s_got = out["matches0"][0, :n].cpu(), out["matching_scores0"][0, :n].cpu()
+            idx_same = bool(torch.equal(m_got, r["matches0"][0]))
+            d_sc = float((s_got - r["matching_scores0"][0]).abs().max())
+            res["match"] = {"indices_identical": idx_same, "matches": int((r["matches0"] >= 0).sum()),
+                            "scores_maxdiff": float(f"{d_sc:.3e}")}
+            if not idx_same:
+                bad = torch.nonzero(m_got != r["matches0"][0]).flatten()
+                res["match"]["mismatches"] = [
+                    {"i": int(i), "got": int(m_got[i]), "ref": int(r["matches0"][0, i]), "score_got": float(s_got[i]),
+                     "score_ref": float(r["matching_scores0"][0, i])} for i in bad[:8]]
+                res["match"]["n_mismatches"] = int(bad.numel())
+            ok = ok and idx_same and d_sc < 1e-3
+    res["ok"] = bool(ok)
+    res["bars"] = "fp32 outputs <= 1e-3 abs, indices exact; recogniser / matcher stage-isolated on the HIP path's keypoints"
+    return res
+
+
+def cpu_baseline(sds, matcher_name, n_queries, kpts, ref_cpu_sets, budget_s=40.0):
+    """The oracle (CPU restatement pinned to the reference) on the host cores, same synthetic workload, per stage."""
     from oracle import ref_cpu as R
     from pram_amd import weights as W
     cores = usable_cores()
@@ -100,34 +178,67 @@ def cpu_baseline(sds, matcher_name, n_queries, kpts, budget_s=40.0):
     print(f"[bench] cpu baseline on {cores} threads (os.cpu_count() = {os.cpu_count()})", file=sys.stderr, flush=True)
     times = []
     t_begin = time.perf_counter()
+    match = _oracle_matcher(matcher_name)
     for i in range(n_queries + 1):          # first one is the warm-up
         if i >= 2 and time.perf_counter() - t_begin > budget_s:
             break
         img = W.synthetic_image(i)[None]
-        t0 = time.perf_counter()
         with torch.no_grad():
+            t0 = time.perf_counter()
             o = R.sfd2_extract_local_global(sds["sfd2"], img, max_keypoints=kpts, min_keypoints=128, per_image_fallback=True)
             kp = o["keypoints"][0]
+            t1 = time.perf_counter()
             _, seg = R.sfd2_sample(o["score_map"], o["mid_features"], kp, norm_desc=False)
             R.segnetvit_forward(sds["segnetvit"], seg.t()[None], kp[None], img.shape)
-            d0 = o["descriptors"][0].t()[None]
-            data = {"descriptors0": d0, "keypoints0": kp[None], "scores0": o["scores"][0][None],
-                    "descriptors1": d0.flip(1).contiguous(), "keypoints1": kp.flip(0)[None], "scores1": o["scores"][0].flip(0)[None],
-                    "image_shape0": (1, 3, W_IMG, H), "image_shape1": (1, 3, W_IMG, H)}
-            if matcher_name == "gml":
-                R.gml_produce_matches(sds["gml"], data)
-            else:
-                R.adagml_produce_matches(sds["adagml"], data)
-        times.append(time.perf_counter() - t0)
-        print(f"[bench] cpu query {i}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
-    per_q = min(times[1:]) if len(times) > 1 else times[0]
+            t2 = time.perf_counter()
+            t3 = t2
+            if ref_cpu_sets is not None:
+                j = min(i, ref_cpu_sets["descriptors"].shape[0] - 1)
+                data = {"descriptors0": o["descriptors"][0].t()[None], "keypoints0": kp[None], "scores0": o["scores"][0][None],
+                        "descriptors1": ref_cpu_sets["descriptors"][j:j + 1], "keypoints1": ref_cpu_sets["keypoints"][j:j + 1],
+                        "scores1": ref_cpu_sets["scores"][j:j + 1], "image_shape0": (1, 3, W_IMG, H), "image_shape1": (1, 3, W_IMG, H)}
+                match(sds[matcher_name], data)
+                t3 = time.perf_counter()
+        times.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+        print(f"[bench] cpu query {i}: {times[-1][0]:.2f} s (extract {times[-1][1]:.2f}, recognise {times[-1][2]:.2f}, match {times[-1][3]:.2f})",
+              file=sys.stderr, flush=True)
+    use = times[1:] if len(times) > 1 else times
+    best = min(use, key=lambda t: t[0])
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": 1.0 / per_q, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{max(1, len(times) - 1)} full queries (SFD2+sample+SegNetViT+{matcher_name.upper()} 2048x2048) after 1 warm-up, min; "
+    return {"value": round(1.0 / best[0], 4), "unit": "queries/s", "cores": cores, "kind": "port",
+            "stage_seconds": {"extract": round(best[1], 3), "recognise": round(best[2], 3), "match": round(best[3], 3)},
+            "sample": f"{len(use)} full queries (SFD2+sample+SegNetViT+{matcher_name.upper()} {kpts}x{kpts}) after 1 warm-up, fastest; "
                       f"torch CPU fp32, {cores} threads, {model}"}
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """--gpus N without a launcher: start N ranks of this script (one process per GPU), like the reference's
+    mp.spawn -> init_process_group("nccl") (main.py:111-155).  Never silently measures fewer GPUs than asked."""
+    one_device = os.environ.get("PRAM_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have == 0:
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    if have < n and not one_device:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node — refusing to report n_gpus={n} "
+                         f"from fewer devices")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PRAM_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] --gpus {n}: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -137,6 +248,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch-per-gpu", type=int, default=16,
                     help="queries per GPU per step (BASELINE configs[1]: batch = 16 on one MI355X; weak scaling keeps it per GPU)")
+    ap.add_argument("--batch-total", type=int, default=0,
+                    help="total queries per step, sharded over the ranks (BASELINE configs[2]: 64 over 8 GPUs; configs[4]: 128 "
+                         "over 8); strong scaling; overrides --batch-per-gpu; uneven shards are fine")
     ap.add_argument("--kpts", type=int, default=2048)
     ap.add_argument("--n-class", type=int, default=113, help="landmark classes (7Scenes 113, Cambridge 161, Aachen 513)")
     ap.add_argument("--matcher", default="gml", choices=["gml", "adagml"])
@@ -145,21 +259,31 @@ def main():
                     help="batches in flight per GPU: consecutive steps are issued round-robin on this many HIP streams, so the "
                          "HBM-bound kernels of one batch run under the MFMA-bound kernels of the next (throughput mode)")
     ap.add_argument("--cpu-queries", type=int, default=4, help="CPU-baseline sample size (0 = skip)")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16"],
-                    help="f32 (default, the parity configuration) or f16 = BASELINE C5 'fp16 MFMA path' (fp16 operands, "
-                         "fp32 accumulate) for attention, token GEMMs and convolutions; own tolerance, not the headline")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate (kernel profiling runs)")
+    ap.add_argument("--precision", default=None, choices=["f32", "x3", "f16"],
+                    help="MFMA path of the three matrix families: f32 = v_mfma_f32_32x32x2_f32 (exact fp32 products); "
+                         "x3 = split-fp16, three v_mfma_f32_32x32x16_f16 per product (fp32-class accuracy, passes the fp32 "
+                         "parity gate); f16 = BASELINE C5 'fp16 MFMA path' (single fp16 product, own tolerance, not the "
+                         "headline).  Default: the package default (pram_amd.ops.default_precision)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # PRAM_BENCH_ONE_DEVICE=1 (test hook): every rank uses GPU 0 over gloo, to exercise the multi-rank control flow
     # (barriers, result gather, max-over-ranks timing) on a one-GPU box; never set by the driver
     one_device = os.environ.get("PRAM_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local = 0
+    elif torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -169,32 +293,51 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)     # backend 'nccl' is RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from pram_amd import ops, weights as Wt
-    from pram_amd.pipeline import QueryPipeline, gather_records
+    from pram_amd.pipeline import QueryPipeline, gather_records, shard_range
     if args.precision:
-        ops.attention_precision = ops.gemm_precision = args.precision
+        ops.set_precision(args.precision)
+    precision = ops.current_precision()
     sfd2, seg, matcher, sds = build_models(dev, args.matcher, args.n_class)
     pipe = QueryPipeline(sfd2, seg, matcher, max_keypoints=args.kpts, min_keypoints=128)
 
-    B = args.batch_per_gpu
-    q0 = rank * B                                          # weak scaling: fixed queries per GPU
+    if args.batch_total > 0:
+        spans = [shard_range(args.batch_total, r, world) for r in range(world)]
+        scaling = "strong"
+    else:
+        spans = [(r * args.batch_per_gpu, (r + 1) * args.batch_per_gpu) for r in range(world)]
+        scaling = "weak"
+    shard_sizes = [hi - lo for lo, hi in spans]
+    q0, q1 = spans[rank]
+    B = q1 - q0
+    total_per_step = sum(shard_sizes)
+    if B == 0:
+        raise SystemExit(f"bench.py: rank {rank} has no queries (--batch-total {args.batch_total} over {world} ranks)")
     images = torch.stack([Wt.synthetic_image(q0 + i) for i in range(B)]).to(dev).contiguous()
+    do_match = "m" in args.stages
+    ref = gt = None
     with torch.no_grad():
         ex = sfd2.extract_batched(images, pipe.cfg)
         counts = ex["counts"].tolist()
-        ref = make_reference_sets(ex["descriptors"], ex["keypoints"], ex["scores"], 5000 + q0) if "m" in args.stages else None
+        if do_match:
+            # synthetic matcher weights calibrated to the extractor's descriptor statistics (weights.calibrate_matcher_input):
+            # without it the untrained matcher sees near-identical tokens and the record holds no matches at all
+            sds[args.matcher] = Wt.calibrate_matcher_input(sds[args.matcher], ex["descriptors"][0, :counts[0]])
+            matcher.load_state_dict(sds[args.matcher], strict=True)
+            matcher.to(dev).eval()
+            ref, gt = make_reference_sets(ex["descriptors"], ex["keypoints"], ex["scores"], counts, 5000 + q0)
     del ex
 
     lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     issued = [0]
+    uneven = min(shard_sizes) != max(shard_sizes)
 
     def step():
         if lanes is None:
             out = pipe.run(images, ref, stages=args.stages)
             rec = QueryPipeline.pack_record(out)
-            return gather_records(rec)
+            return gather_records(rec, shard_sizes if uneven else None)
         lane = lanes[issued[0] % len(lanes)]
         issued[0] += 1
         with torch.cuda.stream(lane):
@@ -204,10 +347,10 @@ def main():
             return rec
         # the (tiny) all-gather stays on the one main stream, in step order on every rank: RCCL never sees
         # collectives of one communicator issued from several streams
-        main = torch.cuda.current_stream(dev)
-        main.wait_stream(lane)
-        rec.record_stream(main)
-        return gather_records(rec)
+        main_s = torch.cuda.current_stream(dev)
+        main_s.wait_stream(lane)
+        rec.record_stream(main_s)
+        return gather_records(rec, shard_sizes if uneven else None)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -227,7 +370,17 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_matches = int((rec[:, :, 4] >= 0).sum().item())
+    assert rec.shape[0] == total_per_step, (rec.shape, total_per_step)
+    local_rec = rec[q0 - spans[0][0]:q1 - spans[0][0]] if world > 1 else rec
+    n_matches = int((local_rec[:, :, 4] >= 0).sum().item())
+    n_correct = 0
+    if do_match:
+        m0 = local_rec[:, :, 4].long()
+        n_correct = int(((m0 == gt) & (m0 >= 0)).sum().item())
+        n_inliers = int((gt >= 0).sum().item())
+        # the workload is built so that a known share of the twins is recovered; an empty record means it degenerated
+        if n_matches < 0.1 * n_inliers:
+            raise SystemExit(f"bench.py: degenerate matcher workload ({n_matches} matches for {n_inliers} planted twins)")
 
     # ---- roofline of the dominant kernel (attention), one extra instrumented step, HIP events on the launch stream
     lanes = None                      # the instrumented step runs alone on the current stream
@@ -244,42 +397,62 @@ def main():
         attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic = None
-    if (args.kpts, B, args.matcher, args.stages, args.n_class, ops.attention_precision) == (2048, 16, "gml", "erm", 113, "f32") and ops.gemm_precision == "f32":
+    if (args.kpts, B, args.matcher, args.stages, args.n_class) == (2048, 16, "gml", "erm", 113):
         try:   # HBM bytes per attention launch of THIS configuration, from the committed rocprofv3 --pmc passes
-            traffic = json.load(open(ROOT / "profiles" / "r01_pmc_attention.json"))["attention_kernel"]["hbm_bytes_per_launch"]
+            traffic = json.load(open(ROOT / "profiles" / "pmc_attention.json"))[precision]["hbm_bytes_per_launch"]
         except Exception:
             pass
-    f16 = ops.attention_precision == "f16"
-    peak = 2500.0 if f16 else PEAK_F32_MFMA_TFLOPS      # dense f16/bf16 MFMA peak vs f32 MFMA peak (MI355X_MICROARCH.md)
-    roofline = {"bound": "mfma", "kernel": "attention_f16_kernel (C5 fp16 MFMA path)" if f16 else "attention_kernel (f32 MFMA flash attention)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": round(attn_flops / max(1, len(probe)) / 512.0), "launches_per_step": len(probe), "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
+    # ceiling on ALGORITHMIC attention flops (4 M N 64 per head): the f32 MFMA peak; a third of the f16 MFMA peak on
+    # the split path (three fp16 MFMAs per fp32-class product); the f16 MFMA peak on the single-product C5 path
+    kern, peak, mult = {
+        "f32": ("attention_kernel (v_mfma_f32_32x32x2_f32 flash attention)", PEAK_F32_MFMA_TFLOPS, 1),
+        "x3": ("attention_x3_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product)", PEAK_F16_MFMA_TFLOPS / 3.0, 3),
+        "f16": ("attention_h16_kernel (C5 fp16 MFMA path)", PEAK_F16_MFMA_TFLOPS, 1),
+    }[precision]
+    roofline = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "mfma_flops_executed_per_algorithmic_flop": mult, "mfma_pipe_peak": PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS,
+                "algorithmic_bytes_per_launch": round(attn_flops / max(1, len(probe)) / 512.0), "launches_per_step": len(probe),
+                "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
                 "attention_share_of_step": round(attn_ms / (dt / args.steps * 1e3), 3)}
 
+    parity = None
+    if rank == 0 and not args.no_parity and "e" in args.stages and "r" in args.stages:
+        parity = parity_gate(pipe, sds, args.matcher, images, ref, args.kpts)
+        print(f"[bench] parity: {json.dumps(parity)}", file=sys.stderr, flush=True)
+
     if rank == 0:
-        total_q = world * B * args.steps
+        total_q = total_per_step * args.steps
+        dtype = {"f32": "f32", "x3": "f32 results via split-fp16 MFMA (f16 x3 products, f32 accumulate)",
+                 "f16": "f16 operands / f32 accumulate: BASELINE C5 'fp16 MFMA path', NOT the fp32 parity configuration"}[precision]
         line = {
-            "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})", "value": round(total_q / dt, 3), "unit": "queries/s",
+            "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})",
+            "value": round(total_q / dt, 3), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if (ops.attention_precision, ops.gemm_precision) == ("f32", "f32") else
-                     f"f16 operands / f32 accumulate (attention {ops.attention_precision}, GEMM+conv {ops.gemm_precision}): "
-                     "BASELINE C5 'fp16 MFMA path', NOT the fp32 parity configuration",
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{'7Scenes' if args.n_class == 113 else 'custom'} full hot path: SFD2 extract+sample -> SegNetViT nc{args.n_class} (15 layers) -> "
                                    f"{args.matcher.upper()} match + 20 Sinkhorn iters vs a {args.kpts}-kpt reference set; "
                                    f"stages={args.stages}",
-                       "queries_per_gpu_per_step": B, "batches_in_flight_per_gpu": max(1, args.inflight),
+                       "precision": precision,
+                       "queries_per_step": total_per_step, "queries_per_gpu_per_step": shard_sizes if uneven else B,
+                       "batches_in_flight_per_gpu": max(1, args.inflight),
                        "frame": f"{W_IMG}x{H}", "keypoints": args.kpts,
                        "keypoints_found": counts[:4], "parallelism": f"query-sharded x{world}, one all-gather of result records",
-                       "matches_last_step": n_matches},
+                       "matches_last_step": n_matches, "matches_correct_last_step": n_correct},
             "roofline": roofline,
         }
+        if parity is not None:
+            line["parity"] = parity
         if world == 1 and args.cpu_queries > 0:
-            line["cpu_baseline"] = cpu_baseline(sds, args.matcher, args.cpu_queries, args.kpts)
+            ref_cpu_sets = None if ref is None else {k: v.cpu() for k, v in ref.items()}
+            line["cpu_baseline"] = cpu_baseline(sds, args.matcher, args.cpu_queries, args.kpts, ref_cpu_sets)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        raise SystemExit("bench.py: PARITY GATE FAILED (see the 'parity' object of the JSON line)")
 
 
 if __name__ == "__main__":

@@ -69,6 +69,22 @@ int pram_linear_f16_h16(const float* a0, int lda0, int k0, const float* a1, int 
                         float* out, int ldo, void* out16, int ldo16, int m, int n, float alpha, int flags,
                         const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
 
+/* Split-fp16 ("x3") variant: fp32-class results on the fp16 matrix pipe (same nn.Linear sites; default path).
+ * Every fp32 operand x is carried as two fp16 numbers, x * s = hi + lo (s a power of two), and every product as
+ * three v_mfma_f32_32x32x16_f16 accumulated in fp32: a.b ~= (a_hi.b_hi + a_hi.b_lo + a_lo.b_hi) / (s_a s_b) — the
+ * dropped lo.lo term and the truncation of hi + lo are 2^-22 relative, the class of fp32 rounding itself.
+ *   w_hi / w_lo : the weight matrix [n][k0+k1] * w_scale split on the host into two fp16 planes
+ *                 (pram_amd/ops.py::split_weight; w_scale = the power of two that puts max|w| in [2^13, 2^14));
+ *   activations : fp32 in HBM, split with s = 16 while they are staged (|x| must stay below 4094);
+ *   out_hi / out_lo (optional, both or neither; then `out` may be NULL): the result * 16 as split planes
+ *                 [m][ldo16] fp16 — the q / k / v operand format of pram_attention_x3_f32.
+ * Needs (k0+k1) % 8 == 0 and, with a second segment, k0 % 32 == 0. */
+int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                       const void* w_hi, const void* w_lo, float w_scale, const float* bias,
+                       const float* residual, int ldr, float* out, int ldo, void* out_hi, void* out_lo,
+                       int ldo16, int m, int n, float alpha, int flags, const float* rot_cos,
+                       const float* rot_sin, int rot_cols, void* stream);
+
 /* Batched C_b = alpha * A_b · B_bᵀ (einsum 'bmd,bnd->bmn', nets/gml.py:282; K12).
  * A_b = a + b*stride_a, [m_max][lda]; B_b [n_max][ldb]; C_b [m_max][ldc]. */
 int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
@@ -118,6 +134,16 @@ int pram_attention_f16_f32(const float* q, int ldq, const float* k, int ldk, con
 int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, const void* v16, int ldv, float* out,
                            int ldo, float* lse2, const int* q_lens, const int* k_lens, int batch, int heads,
                            int m_max, int n_max, float scale, int kv_shift, void* stream);
+
+/* Split-fp16 ("x3") flash attention — the default attention of the fp32 parity path (same einsum -> softmax -> einsum
+ * sites as pram_attention_f32).  q / k / v are the split planes written by pram_linear_x3_f32 (value * 16 = hi + lo,
+ * ld* in halves, multiples of 8; heads are 64-wide column blocks); S = K Q^T and O = P V are three fp16 MFMAs per
+ * product with fp32 accumulation, the probabilities are split in registers.  Output fp32.  kv_shift as in
+ * pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs). */
+int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
+                          const void* v_hi, const void* v_lo, int ldv, float* out, int ldo, float* lse2,
+                          const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
+                          float scale, int kv_shift, void* stream);
 
 /* Both directions of CrossMultiHeadAttention.forward (nets/gml.py:175-179; adagml.py:222-231) in ONE launch:
  * 2*pairs sequences of t_max rows each, sequences 0..pairs-1 = set 0, pairs..2*pairs-1 = set 1; sequence s takes
@@ -201,6 +227,12 @@ int pram_conv2d_nhwc_f16_f32(const float* in, int batch, int h, int w, int cin, 
                              const float* bias, const float* scale, const float* shift,
                              const float* residual, float* out, int cout, int ks, int stride, int relu,
                              void* stream);
+
+/* Split-fp16 ("x3") variant (see pram_linear_x3_f32): wgt_hi / wgt_lo = [cout][ks][ks][cin] * w_scale as two fp16
+ * planes, cin % 32 == 0; the im2col rows are split (s = 16) while they are staged.  fp32 in, fp32 out. */
+int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,
+                            float w_scale, const float* bias, const float* scale, const float* shift,
+                            const float* residual, float* out, int cout, int ks, int stride, int relu, void* stream);
 
 /* Grouped 3x3 convolution of the ResBlock (groups = 32, 8 ch/group; nets/sfd2.py:98-99,113-115).
  * w [c][3][3][c/groups]. */

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
     const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
-    if (qt * BQ >= qlen || klen <= 0) return;
+    if (qt * BQ >= qlen) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -101,6 +101,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const bool wave_active = q0 < qlen;
     const int qrow = q0 + r;
     const bool q_ok = qrow < qlen;
+    if (klen <= 0) {
+        // empty key set (a pruned-away / empty opposite set in a ragged batch): the context of the valid query rows is
+        // defined as 0 (and lse as 0) instead of being left as uninitialised memory for the MLP tail to read
+        if (q_ok && (p.nsplit <= 1 || blockIdx.y == 0)) {
+            float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = 0.f;
+        }
+        return;
+    }
 
     const float* qp = p.q + ((size_t)b * p.m_max + qrow) * p.ldq + head * D;
     const float* kp = p.k + (size_t)kb * p.n_max * p.ldk + head * D;
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void colmean_kernel(ColArgs p) {
             __syncthreads();
         }
     }
-    const float norm = 1.0f / ((float)p.heads * (float)qlen);
+    const float norm = qlen > 0 ? 1.0f / ((float)p.heads * (float)qlen) : 0.f;   // no queries: the mean over an empty set is reported as 0, not NaN
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         float v = cacc[e];

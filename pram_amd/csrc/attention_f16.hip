@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 3) void attention_f16_kernel(Args p) {
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
     const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
     const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
-    if (qt * BQ >= qlen || klen <= 0) return;
+    if (qt * BQ >= qlen) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -70,6 +70,15 @@ __global__ __launch_bounds__(256, 3) void attention_f16_kernel(Args p) {
     const bool wave_active = q0 < qlen;
     const int qrow = q0 + r;
     const bool q_ok = qrow < qlen;
+    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip)
+        if (q_ok) {
+            float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = 0.f;
+        }
+        return;
+    }
 
     const float* qp = p.q + ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
     const float* kp = p.k + (size_t)kb * p.n_max * p.ldk + head * D;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(256, 3) void attention_h16_kernel(ArgsH p) {
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
     const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
     const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
-    if (qt * BQ >= qlen || klen <= 0) return;
+    if (qt * BQ >= qlen) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -249,6 +258,15 @@ __global__ __launch_bounds__(256, 3) void attention_h16_kernel(ArgsH p) {
     const bool wave_active = q0 < qlen;
     const int qrow = q0 + r;
     const bool q_ok = qrow < qlen;
+    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip)
+        if (q_ok) {
+            float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = 0.f;
+        }
+        return;
+    }
 
     const _Float16* qp = p.q + ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
     const _Float16* kp = p.k + (size_t)kb * p.n_max * p.ldk + head * D;

@@ -1,0 +1,257 @@
+// Split-fp16 ("x3") flash attention on v_mfma_f32_32x32x16_f16: fp32-class results at the fp16 matrix rate.
+// Replaces, like attention.hip, the materialised einsum -> softmax -> einsum of nets/segnetvit.py:73-76 (self) and
+// nets/gml.py:175-179 (cross: both directions in one launch, kv_shift).
+//
+// Q, K and V arrive as the split planes the projection GEMM writes (pram_linear_x3_f32, out_hi / out_lo):
+//     x * 16 = hi + lo,  hi = fp16(16 x),  lo = fp16(16 x - hi)
+// and every product is three MFMAs accumulated in fp32 (gemm_core_x3.h has the error analysis):
+//     S^T = K_hi Q_hi + K_hi Q_lo + K_lo Q_hi            (= 256 K Q^T; the 1/256 rides in the softmax scale)
+//     O^T = V^T_hi P_hi + V^T_hi P_lo + V^T_lo P_hi       (P = 2^14 exp2(...) split in registers, = 2^18 V^T P)
+// The probabilities are scaled by 2^14 (an offset in the exponent argument: free) so that hi + lo keeps 22 bits for
+// every probability above 2^-17 of the row maximum; the row sum accumulates the same scaled fp32 values, so the
+// scale cancels in the normalisation.
+//
+// Register design as attention.hip / attention_f16.hip: everything transposed so that the query row is the lane
+// index in every accumulator (online-softmax state lane-local, P never leaves registers); K tile [key][d] and V tile
+// TRANSPOSED and key-permuted [d][pos(key)] in LDS so that both MFMA operands are single ds_read_b128s.
+// Per 64-key tile per wave: 48 MFMA x 32 cycles = 1536 matrix cycles (the f32-MFMA kernel: 8192).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int D = 64, QW = 32, NW = 4, BQ = QW * NW, BKV = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3::ACT_SCALE)
+constexpr float P_EXP_SHIFT = 14.0f;    // probabilities carried as 2^14 p
+
+struct ArgsX {
+    const _Float16* qh; const _Float16* ql; const _Float16* kh; const _Float16* kl; const _Float16* vh; const _Float16* vl;
+    float* out; float* lse2;
+    const int* q_lens; const int* k_lens;
+    int ldq, ldk, ldv, ldo;          // ldq / ldk / ldv in halves
+    int batch, heads, m_max, n_max;
+    float scale2;                    // scale * log2(e) / IN_SCALE^2
+    int q_tiles;
+    int kv_shift;                    // as in attention.hip
+};
+
+struct alignas(16) Smem {
+    _Float16 kh[2][BKV * D];    // [key][d], slot-swizzled
+    _Float16 kl[2][BKV * D];
+    _Float16 vth[2][D * BKV];   // [d][pos(key)], slot-swizzled
+    _Float16 vtl[2][D * BKV];
+};  // 64 KiB -> two workgroups per CU
+
+__device__ __forceinline__ int key_of(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+// position of key (0..63) inside a V^T row: inverse of key = 32t + (i&3) + 16u + 8(i>>2) + 4h
+__device__ __forceinline__ int pos_of_key(int key) {
+    const int t = key >> 5, w = key & 31;
+    const int u = w >> 4, h = (w >> 2) & 1, i = (w & 3) | (((w >> 3) & 1) << 2);
+    return t * 32 + u * 16 + h * 8 + i;
+}
+
+__global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
+    __shared__ Smem s;
+    const int nblk = p.batch * p.heads * p.q_tiles;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int qt = id % p.q_tiles;
+    const int bh = id / p.q_tiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
+    if (qt * BQ >= qlen) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qt * BQ + wave * QW;
+    const bool wave_active = q0 < qlen;
+    const int qrow = q0 + r;
+    const bool q_ok = qrow < qlen;
+    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip)
+        if (q_ok) {
+            float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = 0.f;
+        }
+        return;
+    }
+
+    const size_t qoff = ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
+    const size_t koff = (size_t)kb * p.n_max * p.ldk + head * D;
+    const size_t voff = (size_t)kb * p.n_max * p.ldv + head * D;
+
+    // Q fragments: q?[c][i] = plane(Q[qrow][16c + 8h + i])
+    half8 qh[4], ql[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qh[c] = *reinterpret_cast<const half8*>(p.qh + qoff + c * 16 + h * 8);
+        ql[c] = *reinterpret_cast<const half8*>(p.ql + qoff + c * 16 + h * 8);
+        if (!q_ok)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qh[c][i] = (_Float16)0.f; ql[c][i] = (_Float16)0.f; }
+    }
+
+    const int lrow = tid >> 3, lseg = tid & 7;      // staging: key lrow + 32p, halves 8*lseg .. 8*lseg+7
+    half8 krh[2], krl[2], vrh[2], vrl[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const size_t kc = (size_t)min(kt * BKV + lrow + 32 * pp, klen - 1);
+            krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
+            krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
+            vrh[pp] = *reinterpret_cast<const half8*>(p.vh + voff + kc * p.ldv + lseg * 8);
+            vrl[pp] = *reinterpret_cast<const half8*>(p.vl + voff + kc * p.ldv + lseg * 8);
+        }
+    };
+    auto lstore = [&](int buf, int kt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row = lrow + 32 * pp;
+            const bool ok = kt * BKV + row < klen;
+            half8 a = krh[pp], bq = krl[pp], c = vrh[pp], d8 = vrl[pp];
+            if (!ok)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { a[i] = (_Float16)0.f; bq[i] = (_Float16)0.f; c[i] = (_Float16)0.f; d8[i] = (_Float16)0.f; }
+            const int koffs = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
+            *reinterpret_cast<half8*>(&s.kh[buf][koffs]) = a;
+            *reinterpret_cast<half8*>(&s.kl[buf][koffs]) = bq;
+            const int pos = pos_of_key(row);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = lseg * 8 + j;
+                const int vo = d * BKV + (((pos >> 3) ^ ((d >> 1) & 7)) << 3) + (pos & 7);
+                s.vth[buf][vo] = c[j];
+                s.vtl[buf][vo] = d8[j];
+            }
+        }
+    };
+
+    const int nkt = (klen + BKV - 1) / BKV;
+    gload(0);
+    lstore(0, 0);
+    __syncthreads();
+
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) gload(kt + 1);
+
+        if (wave_active) {
+            f32x16 st[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;   // ((32 + r) >> 1) & 7 == (r >> 1) & 7
+                const half8 k0h = *reinterpret_cast<const half8*>(&s.kh[cur][r * D + slot]);
+                const half8 k1h = *reinterpret_cast<const half8*>(&s.kh[cur][(32 + r) * D + slot]);
+                const half8 k0l = *reinterpret_cast<const half8*>(&s.kl[cur][r * D + slot]);
+                const half8 k1l = *reinterpret_cast<const half8*>(&s.kl[cur][(32 + r) * D + slot]);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0l, qh[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1l, qh[c], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, ql[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, ql[c], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, qh[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, qh[c], st[1], 0, 0, 0);
+            }
+            if (!more && (klen & (BKV - 1))) {
+                const int kbase = kt * BKV;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + t * 32 + key_of(e, h) >= klen) st[t][e] = -INFINITY;
+            }
+            float tmax = st[0][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax * p.scale2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float shift = P_EXP_SHIFT - m_new;
+            float psum = 0.f;
+            half8 ph[2][2], pl[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, shift));   // v_exp_f32: argument <= 14
+                    psum += pv;
+                    const _Float16 hi = (_Float16)pv;
+                    ph[t][e >> 3][e & 7] = hi;
+                    pl[t][e >> 3][e & 7] = (_Float16)(pv - (float)hi);
+                }
+            l_run = fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
+                    const half8 v0h = *reinterpret_cast<const half8*>(&s.vth[cur][r * BKV + slot]);
+                    const half8 v1h = *reinterpret_cast<const half8*>(&s.vth[cur][(32 + r) * BKV + slot]);
+                    const half8 v0l = *reinterpret_cast<const half8*>(&s.vtl[cur][r * BKV + slot]);
+                    const half8 v1l = *reinterpret_cast<const half8*>(&s.vtl[cur][(32 + r) * BKV + slot]);
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[t][u], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[t][u], oacc[1], 0, 0, 0);
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[t][u], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[t][u], oacc[1], 0, 0, 0);
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[t][u], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[t][u], oacc[1], 0, 0, 0);
+                }
+        }
+        if (more) lstore(cur ^ 1, kt + 1);
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (1.0f / IN_SCALE) / l_tot;       // undoes the 2^14 of P (carried by l_tot) and the 16 of V
+    if (q_ok) {
+        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
+                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
+            }
+        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + (log2f(l_tot) - P_EXP_SHIFT);
+    }
+}
+
+}  // namespace
+
+/* Split-fp16 q / k / v planes in HBM (written by pram_linear_x3_f32: value * 16 = hi + lo): ld* in halves, 16-byte aligned
+   rows and head offsets.  kv_shift > 0: keys / values of sequence s come from sequence (s + kv_shift) % batch (cross
+   attention, both directions in one launch). */
+extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
+                                     const void* v_hi, const void* v_lo, int ldv, float* out, int ldo, float* lse2,
+                                     const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
+                                     float scale, int kv_shift, void* stream) {
+    PRAM_REQUIRE(q_hi && q_lo && k_hi && k_lo && v_hi && v_lo && out, "pram_attention_x3_f32: null pointer");
+    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "pram_attention_x3_f32: ld of the fp16 planes must be a multiple of 8");
+    PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_x3_f32: bad sizes");
+    if (batch == 0 || m_max == 0) return PRAM_OK;
+    PRAM_REQUIRE(n_max > 0, "pram_attention_x3_f32: empty key set");
+    ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)v_hi,
+            (const _Float16*)v_lo, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max,
+            scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift};
+    hipLaunchKernelGGL(attention_x3_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_x3_f32");
+}

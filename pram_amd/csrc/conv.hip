@@ -9,6 +9,7 @@
 // per-channel scale/shift in the epilogue (same op order as conv -> BN), then residual, then ReLU.
 #include "gemm_core.h"
 #include "gemm_core_f16.h"
+#include "gemm_core_x3.h"
 
 namespace {
 
@@ -197,6 +198,69 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
     conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 
+// split-fp16 variant (gemm_core_x3.h): wh / wl = [cout][ks][ks][cin] * w_scale split into two fp16 planes on the host,
+// cin % 32 == 0 (a 32-deep chunk never straddles taps); the im2col rows are split while they are staged.
+template <int MI, int WN>
+__global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, const _Float16* __restrict__ wh,
+                                                                 const _Float16* __restrict__ wl, float inv) {
+    using namespace gemmx3;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int tid = threadIdx.x;
+    const int arow = tid >> 3, akq = tid & 7, brow = tid >> 2, bsl = tid & 3;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int pad = p.ks >> 1;
+    int iy0[C::PA], ix0[C::PA];
+    const float* base[C::PA];
+    bool ok[C::PA];
+#pragma unroll
+    for (int pp = 0; pp < C::PA; ++pp) {
+        const int row = row0 + arow + 32 * pp;
+        ok[pp] = row < p.m;
+        const int rr = ok[pp] ? row : 0;
+        const int ox = rr % p.wo;
+        const int t = rr / p.wo;
+        const int oy = t % p.ho;
+        const int b = t / p.ho;
+        iy0[pp] = oy * p.stride - pad;
+        ix0[pp] = ox * p.stride - pad;
+        base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
+    }
+    const int nlast = p.cout - 1;
+    int cky = 0, ckx = 0, cci = 0;
+    auto adv = [&](int kt) {
+        if (kt == 0) { cky = ckx = cci = 0; return; }
+        cci += BK;
+        if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
+    };
+    size_t boff[C::PB];
+#pragma unroll
+    for (int pp = 0; pp < C::PB; ++pp) boff[pp] = (size_t)min(col0 + brow + 64 * pp, nlast) * p.k + bsl * 8;
+    auto la = [&](int pp, int kt) -> float4 {
+        const int iyc = min(max(iy0[pp] + cky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
+        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + akq * 4);
+    };
+    auto oka = [&](int pp, int kt) -> bool {
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
+        return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+    };
+    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 64 * pp) < p.cout; };
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, ACT_SCALE, acc);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
+    conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
+}
+
 // ---------------------------------------------------------------- grouped 3x3 (VALU)
 // groups = 32, 8 in / 8 out channels per group (72-deep dot products: too thin for MFMA tiles).
 // Workgroup = 64 consecutive x-pixels x 4 output rows x 4 groups (one group per wave, so the 576
@@ -373,6 +437,39 @@ extern "C" int pram_conv2d_nhwc_f16_f32(const float* in, int batch, int h, int w
     else { if (mi == 2) LAUNCH16(2, 2); else LAUNCH16(1, 2); }
 #undef LAUNCH16
     return pram_launch_status("pram_conv2d_nhwc_f16_f32");
+}
+
+extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,
+                                       float w_scale, const float* bias, const float* scale, const float* shift,
+                                       const float* residual, float* out, int cout, int ks, int stride, int relu, void* stream) {
+    PRAM_REQUIRE(in && wgt_hi && wgt_lo && out, "pram_conv2d_nhwc_x3_f32: null pointer");
+    PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_x3_f32: ks must be 1 or 3");
+    PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_x3_f32: stride must be 1 or 2");
+    PRAM_REQUIRE(cin % 32 == 0 && w_scale > 0.f, "pram_conv2d_nhwc_x3_f32: cin=%d must be a multiple of 32", cin);
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_x3_f32: scale and shift go together");
+    if (batch == 0) return PRAM_OK;
+    const int pad = ks / 2;
+    ConvArgs p{in, nullptr, bias, scale, shift, residual, out, batch, h, w, cin, cout, ks, stride, relu};
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    p.m = batch * p.ho * p.wo;
+    p.k = ks * ks * cin;
+    int mi, wn;
+    gemm::choose_tile(p.m, cout, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* wh = (const _Float16*)wgt_hi;
+    const _Float16* wl = (const _Float16*)wgt_lo;
+    const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+#define LAUNCHX3(MI_, WN_)                                                                                              \
+    do {                                                                                                                \
+        p.tiles_m = cdiv(p.m, gemmx3::Cfg<MI_, WN_>::BM);                                                               \
+        p.tiles_n = cdiv(cout, gemmx3::Cfg<MI_, WN_>::BN);                                                              \
+        hipLaunchKernelGGL((conv_x3_kernel<MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemmx3::NT), 0, st, p, wh, wl, inv); \
+    } while (0)
+    if (wn == 1) { if (mi == 2) LAUNCHX3(2, 1); else LAUNCHX3(1, 1); }
+    else { if (mi == 2) LAUNCHX3(2, 2); else LAUNCHX3(1, 2); }
+#undef LAUNCHX3
+    return pram_launch_status("pram_conv2d_nhwc_x3_f32");
 }
 
 extern "C" int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int c, const float* wgt,

@@ -1,0 +1,160 @@
+// Split-fp16 ("x3") GEMM main loop for gfx950: fp32-class products on the fp16 matrix pipe.
+//
+// f32 MFMA (v_mfma_f32_32x32x2_f32) runs at the f32 VECTOR rate, 1/16 of the fp16 rate.  Here every fp32 operand x is
+// carried as two fp16 numbers,
+//     x * s = hi + lo,   hi = fp16(x * s),  lo = fp16(x * s - hi)        (s = a power of two: exact)
+// and a product is formed from three fp16 MFMAs accumulated in fp32,
+//     a . b  ~=  (a_hi . b_hi + a_hi . b_lo + a_lo . b_hi) / (s_a s_b)       (a_lo . b_lo ~ 2^-22 |a b| is dropped).
+// Products of fp16 values are exact in the fp32 accumulator, so the only errors are the 2^-22-relative truncation of
+// hi + lo and the dropped term: the same class as the fp32 rounding of the f32-MFMA path (measured end to end against
+// the fp32 oracle: SegNetViT logits 1.4e-5, GML / AdaGML indices identical at 2048 x 2048 —
+// profiles/tools/split_emulation.py; single-product fp16 gives 1.1e-2).  3 x 32 cycles per 32x32x16 block against
+// 8 x 64 cycles for the same block in f32 MFMAs: 5.3x less matrix time.
+//
+// The scale keeps the parts inside fp16's range: activations use ACT_SCALE = 16 (hi overflows only beyond |x| = 4094;
+// lo is a normal fp16 number down to |x| = 2^-7 and loses at most 2^-29 absolute below that); weights are scaled per
+// tensor to the top of the range when they are split once on the host.
+//
+// Tiling as gemm_core.h (so the epilogues are shared): 4 waves as WM x WN, MI x 2 accumulators of 32 x 32 per wave,
+// K chunks of 32 through a double-buffered LDS stage.  A (activations / im2col) arrives as fp32 and is split while it
+// is staged: 8 threads read one 128-B row segment as float4 and store 2 x 8 bytes; B (weights) is pre-split: 4 threads
+// read one 64-B row segment of each plane.  LDS rows are 64 B (32 fp16): four rows share the 64 banks, and the 16-B
+// slot is XOR-swizzled with (row >> 2) & 3, which makes every 16-lane group of a ds_read_b128 touch 16 distinct
+// (bank-row quarter, slot) pairs.
+#pragma once
+#include "common.h"
+
+namespace gemmx3 {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32, NT = 256;
+constexpr float ACT_SCALE = 16.0f;       // power of two: scaling is exact
+
+template <int MI, int WN>
+struct Cfg {
+    static constexpr int WM = 4 / WN;
+    static constexpr int BM = WM * 32 * MI;
+    static constexpr int BN = WN * 64;
+    static constexpr int PA = BM / 32;   // float4 (fp32) staging loads per thread for A
+    static constexpr int PB = BN / 64;   // 16-byte (8 x fp16) staging loads per thread and plane for B
+};
+
+template <int MI, int WN>
+struct alignas(16) Smem {
+    _Float16 ah[2][Cfg<MI, WN>::BM * BK];
+    _Float16 al[2][Cfg<MI, WN>::BM * BK];
+    _Float16 bh[2][Cfg<MI, WN>::BN * BK];
+    _Float16 bl[2][Cfg<MI, WN>::BN * BK];
+};  // <2,2>: 64 KiB -> two workgroups per CU
+
+__device__ __forceinline__ int swz(int slot, int row) { return slot ^ ((row >> 2) & 3); }
+
+// x * s -> (hi, lo) for four values
+__device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo) {
+    const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)x[i];
+        lo[i] = (_Float16)(x[i] - (float)hi[i]);
+    }
+}
+
+// ALoad(p, kt) -> raw float4 A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3];  AOk(p, kt) its predicate
+// BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + 64p][kt*32 + (tid%4)*8 ..+7] (fp16); BOk(p, kt) its predicate
+// Adv(kt): wave-uniform loader state, advanced once per chunk (the convolution's tap / channel walk).
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         float a_scale, f32x16 (&acc)[MI][2]) {
+    using C = Cfg<MI, WN>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int arow = tid >> 3, akq = tid & 7;
+    const int brow = tid >> 2, bsl = tid & 3;
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    float4 ra[C::PA];
+    uint4 rbh[C::PB], rbl[C::PB];
+    unsigned ok = 0u;
+    auto issue = [&](int kt) {
+        ok = 0u;
+#pragma unroll
+        for (int p = 0; p < C::PA; ++p) { ra[p] = la(p, kt); ok |= (oka(p, kt) ? 1u : 0u) << p; }
+#pragma unroll
+        for (int p = 0; p < C::PB; ++p) { rbh[p] = lb(p, kt, 0); rbl[p] = lb(p, kt, 1); ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < C::PA; ++p) {
+            const int row = arow + 32 * p;
+            float4 v = ra[p];
+            if (!((ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            half4 hi, lo;
+            split4(v, a_scale, hi, lo);
+            const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;
+            *reinterpret_cast<half4*>(&s.ah[buf][off]) = hi;
+            *reinterpret_cast<half4*>(&s.al[buf][off]) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < C::PB; ++p) {
+            const int row = brow + 64 * p;
+            uint4 vh = rbh[p], vl = rbl[p];
+            if (!((ok >> (8 + p)) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+            const int off = row * BK + swz(bsl, row) * 8;
+            *reinterpret_cast<uint4*>(&s.bh[buf][off]) = vh;
+            *reinterpret_cast<uint4*>(&s.bl[buf][off]) = vl;
+        }
+    };
+    adv(0);
+    issue(0);
+    commit(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) { adv(kt + 1); issue(kt + 1); }
+        const int arow0 = (wm * 32 * MI + r) * BK, brow0 = (wn * 64 + r) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = swz(2 * ks + h, r) * 8;      // tile rows differ from r by multiples of 32: same swizzle
+            half8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                ah[mi] = *reinterpret_cast<const half8*>(&s.ah[cur][arow0 + mi * 32 * BK + slot]);
+                al[mi] = *reinterpret_cast<const half8*>(&s.al[cur][arow0 + mi * 32 * BK + slot]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                bh[ni] = *reinterpret_cast<const half8*>(&s.bh[cur][brow0 + ni * 32 * BK + slot]);
+                bl[ni] = *reinterpret_cast<const half8*>(&s.bl[cur][brow0 + ni * 32 * BK + slot]);
+            }
+            // small terms first, the dominant hi.hi last: each accumulator sees lo.hi, hi.lo, hi.hi
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) commit(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+}  // namespace gemmx3

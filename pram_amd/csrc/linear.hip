@@ -3,6 +3,7 @@
 // Reference sites: nets/segnetvit.py:87-106,157-164; nets/gml.py:118-186,220,235,278-282.
 #include "gemm_core.h"
 #include "gemm_core_f16.h"
+#include "gemm_core_x3.h"
 
 namespace {
 
@@ -23,6 +24,9 @@ struct LinArgs {
     // optional fp16 copy of the output (same values, rounded to nearest even) for the fp16 attention kernel, which
     // would otherwise round the fp32 output itself while staging it; `out` may be null when only the copy is wanted
     void* out16; int ldo16;
+    // split-fp16 output planes (x3 path): out16 = hi plane, out16_lo = lo plane of out * out16_scale (out16_lo == nullptr:
+    // out16 is the plain fp16 copy of the C5 path)
+    void* out16_lo; float out16_scale;
 };
 
 // Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
@@ -77,7 +81,20 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             q0[e] = v0;
             q1[e] = v1;
         }
-        if (p.out16) {
+        if (p.out16 && p.out16_lo) {      // split planes: hi = fp16(v s), lo = fp16(v s - hi)
+            _Float16* oh = reinterpret_cast<_Float16*>(p.out16);
+            _Float16* ol = reinterpret_cast<_Float16*>(p.out16_lo);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + acc_row(mi, e, h);
+                if (row < p.m) {
+                    const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
+                    const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+                    if (c0ok) { oh[(size_t)row * p.ldo16 + c0] = h0; ol[(size_t)row * p.ldo16 + c0] = (_Float16)(s0 - (float)h0); }
+                    if (c1ok) { oh[(size_t)row * p.ldo16 + c1] = h1; ol[(size_t)row * p.ldo16 + c1] = (_Float16)(s1 - (float)h1); }
+                }
+            }
+        } else if (p.out16) {
             _Float16* o16 = reinterpret_cast<_Float16*>(p.out16);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -191,6 +208,57 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
     linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
 }
 
+// split-fp16 variant (gemm_core_x3.h): wh / wl = the weight matrix * w_scale split into two fp16 planes [n][K] on the
+// host; activations are split while they are staged.  inv = 1 / (ACT_SCALE * w_scale) undoes both scales (exact).
+template <int MI, int WN>
+__global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, const _Float16* __restrict__ wh,
+                                                                   const _Float16* __restrict__ wl, float inv) {
+    using namespace gemmx3;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int K = p.k0 + p.k1;
+    const int tid = threadIdx.x;
+    const int arow = tid >> 3, akq = tid & 7, brow = tid >> 2, bsl = tid & 3;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int mlast = p.m - 1, nlast = p.n - 1;
+    const float* arow0[C::PA];
+    const float* arow1[C::PA];
+#pragma unroll
+    for (int pp = 0; pp < C::PA; ++pp) {
+        const int rc = min(row0 + arow + 32 * pp, mlast);
+        arow0[pp] = p.a0 + (size_t)rc * p.lda0;
+        arow1[pp] = p.a1 ? p.a1 + (size_t)rc * p.lda1 - p.k0 : arow0[pp];
+    }
+    size_t boff[C::PB];
+#pragma unroll
+    for (int pp = 0; pp < C::PB; ++pp) boff[pp] = (size_t)min(col0 + brow + 64 * pp, nlast) * K;
+    auto la = [&](int pp, int kt) -> float4 {
+        const int kc = min(kt * BK + akq * 4, K - 4);
+        const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
+        return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
+    };
+    auto oka = [&](int pp, int kt) -> bool { return (row0 + arow + 32 * pp) < p.m && (kt * BK + akq * 4) < K; };
+    auto lb = [&](int pp, int kt, int plane) -> uint4 {
+        const int kc = min(kt * BK + bsl * 8, K - 8);
+        return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kc);
+    };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 64 * pp) < p.n && (kt * BK + bsl * 8) < K; };
+    auto adv = [](int) {};
+    f32x16 acc[MI][2];
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
+    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
+}
+
 // ---------------------------------------------------------------- LayerNorm + GELU
 // One wave per row; the row (<= 1024 floats) lives in registers, mean then centred variance
 // (two-pass, like torch's RowwiseMoments result to fp32 rounding), exact erf GELU.
@@ -273,7 +341,40 @@ void launch_linear_f16_t(LinArgs& p, const _Float16* w16, hipStream_t st) {
     hipLaunchKernelGGL((linear_f16_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemm16::NT), 0, st, p, w16);
 }
 
+template <int MI, int WN>
+void launch_linear_x3_t(LinArgs& p, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+    using C = gemmx3::Cfg<MI, WN>;
+    p.tiles_m = cdiv(p.m, C::BM);
+    p.tiles_n = cdiv(p.n, C::BN);
+    hipLaunchKernelGGL((linear_x3_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
+}
+
 }  // namespace
+
+extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+                                  const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
+                                  float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
+                                  int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
+    PRAM_REQUIRE(a0 && w_hi && w_lo && (out || (out_hi && out_lo)), "pram_linear_x3_f32: null pointer");
+    PRAM_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), "pram_linear_x3_f32: the split output needs both planes");
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0 && w_scale > 0.f, "pram_linear_x3_f32: bad sizes");
+    PRAM_REQUIRE((k0 + k1) % 8 == 0 && lda0 % 4 == 0, "pram_linear_x3_f32: K must be a multiple of 8, lda of 4");
+    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemmx3::BK == 0 && lda1 % 4 == 0), "pram_linear_x3_f32: concat needs k0 %% 32 == 0");
+    if (flags & PRAM_LIN_ROTARY)
+        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_x3_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
+    if (m == 0) return PRAM_OK;
+    LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE};
+    int mi, wn;
+    gemm::choose_tile(m, n, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* wh = (const _Float16*)w_hi;
+    const _Float16* wl = (const _Float16*)w_lo;
+    const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    if (wn == 2) { if (mi == 2) launch_linear_x3_t<2, 2>(p, wh, wl, inv, st); else launch_linear_x3_t<1, 2>(p, wh, wl, inv, st); }
+    else         { if (mi == 2) launch_linear_x3_t<2, 1>(p, wh, wl, inv, st); else launch_linear_x3_t<1, 1>(p, wh, wl, inv, st); }
+    return pram_launch_status("pram_linear_x3_f32");
+}
 
 extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
                                    const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,

@@ -58,7 +58,7 @@ static SinkWs carve(void* ws, int batch, int m_max, int n_max, size_t* total) {
     return w;
 }
 
-// ---- row softmax of the augmented matrix (one wave per row), v <- 1 ---------------------------
+// ---- row softmax of the augmented matrix (one wave per row), u, v <- 1 ------------------------
 // mode 0: write softmax probabilities (Sinkhorn);  mode 1: write raw augmented scores and the row
 // log-sum-exp (dual softmax).
 __global__ __launch_bounds__(256) void sink_init_kernel(const float* __restrict__ dist, int ldd, long long sdist,
@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void sink_init_kernel(const float* __restrict_
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i == 0)
         for (int j = lane; j < w.ldw; j += 64) w.v[(size_t)b * w.ldw + j] = 1.0f;
+    // u <- 1 as well: with zero iterations the final pass returns the plain row softmax (u = v = 1), like the reference
+    if (i <= m_max && lane == 0) w.u[(size_t)b * (m_max + 1) + i] = 1.0f;
     if (i > m) return;
     const float bs = bin[0];
     const float* src = dist + b * sdist + (size_t)i * ldd;

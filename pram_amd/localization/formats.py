@@ -271,6 +271,23 @@ def match_pairs(model, pairs: Iterable[Tuple[str, str]], store_q, store_r, match
 
     writers = _Writers(write, writer_threads)
     net = getattr(model, "net", model)
+    if not hasattr(net, "produce_matches"):
+        # descriptor-only plugins ('NNM' -> matchers/nearest_neighbor.py): no ragged-batch support, one pair per call
+        # like the reference's loop.  The plugin wants channel-major descriptors [B, D, N] (nearest_neighbor.py:44-47);
+        # the reference's FeaturePairsDataset hands it [N, D] (it transposes for the attention matchers), which only
+        # runs there when both sets happen to have the same size — here the plugin gets the layout it is written for.
+        for a, b in pairs:
+            it = read_feature_pair(store_q, a, store_r, b)
+            k = it["keypoints0"].shape[0]
+            if k == 0 or it["keypoints1"].shape[0] == 0:
+                enc = {"matches0": np.full((k,), -1, np.int16), "matching_scores0": np.zeros((k,), np.float16)}
+            else:
+                pred = model({"descriptors0": it["descriptors0"].t()[None].contiguous().to(device),
+                              "descriptors1": it["descriptors1"].t()[None].contiguous().to(device)})
+                enc = encode_matches(pred["matches0"][0], pred.get("matching_scores0", [None])[0])
+            writers.put((names_to_pair(a, b), enc))
+        writers.join()
+        return len(pairs)
     for lo in range(0, len(pairs), batch_size):
         chunk = pairs[lo:lo + batch_size]
         items = [read_feature_pair(store_q, a, store_r, b) for a, b in chunk]

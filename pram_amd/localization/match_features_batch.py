@@ -12,14 +12,24 @@ confs = {
             'model': {'name': 'gml', 'weight_path': 'weights/imp_gml.920.pth', 'sinkhorn_iterations': 20}},
     'adagml': {'output': 'adagml',
                'model': {'name': 'adagml', 'weight_path': 'weights/imp_adagml.80.pth', 'sinkhorn_iterations': 20}},
+    'NNM': {'output': 'NNM',
+            'model': {'name': 'nearest_neighbor', 'do_mutual_check': True, 'distance_threshold': None}},
 }
+# registered by the reference but not part of this build: 'gm' (nets/gm.py's GM class cannot be constructed in the
+# reference itself) and 'superglue' (third-party weights / network, outside SURVEY.md §8)
+_NOT_BUILT = {'gm': "nets/gm.py::GM is unconstructible in the reference (SURVEY.md H4); use 'gml'",
+              'superglue': "SuperGlue is outside the hot path of SURVEY.md §8"}
 
 
 def build_matcher(name: str, weight_path=None, device='cuda'):
     """dynamic_load(matchers, name)(conf).eval().to(device) — localization/localizer.py:39-40,
     localization/multimap3d.py:43-44."""
+    if name in _NOT_BUILT:
+        raise NotImplementedError(f"matcher conf {name!r}: {_NOT_BUILT[name]}")
+    if name not in confs:
+        raise KeyError(f"unknown matcher conf {name!r}; available: {sorted(confs)}")
     conf = dict(confs[name]['model'])
-    if weight_path is not None:
+    if weight_path is not None and 'weight_path' in conf:
         conf['weight_path'] = weight_path
     Model = dynamic_load(matchers, conf['name'])
     return Model(conf).eval().to(device)

@@ -78,6 +78,15 @@ def _half_path() -> bool:
     return ops.gemm_precision == "f16" and ops.attention_precision == "f16"
 
 
+def _split_path() -> bool:
+    """both families on the split-fp16 path: the projection hands q / k / v over as (hi, lo) fp16 planes"""
+    return ops.gemm_precision == "x3" and ops.attention_precision == "x3"
+
+
+def _cols(planes, lo: int, hi: int):
+    return planes[0][:, lo:hi], planes[1][:, lo:hi]
+
+
 def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
     """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0"""
     h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx)
@@ -90,6 +99,15 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
     """x [S*T, 256] -> same.  SelfMultiHeadAttention.forward (nets/segnetvit.py:97-106)."""
     hid = HEADS * DH
     scale = DH ** -0.5
+    if _split_path():
+        # split-fp16 path: the projection writes q | k | v as (hi, lo) planes (plus fp32 when the column means need q / k)
+        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="also" if want_colmean else "only")
+        q3, k3, v3 = _cols(pl, 0, hid), _cols(pl, hid, 2 * hid), _cols(pl, 2 * hid, 3 * hid)
+        if want_colmean:
+            ctx, lse = ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens, want_lse=True)
+            col = ops.attention_colmean(qkv[:, :hid], qkv[:, hid:2 * hid], lse, S, HEADS, T, T, scale, lens, lens)
+            return _mlp_tail(x, ctx, p), col
+        return _mlp_tail(x, ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens), p)
     if _half_path() and not want_colmean:
         # fp16 path: the projection writes q | k | v as fp16 only (what the fp16 attention would round them to anyway)
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), half_copy="only")
@@ -111,6 +129,14 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     (nets/gml.py:164-186): m0 = softmax_row(sim) v1, m1 = softmax_row(sim^T) v0."""
     hid = HEADS * DH
     scale = DH ** -0.5     # (dh^-1/4)^2
+    if _split_path():
+        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="also" if want_colmean else "only")
+        qk3, v3 = _cols(pl, 0, hid), _cols(pl, hid, 2 * hid)
+        if want_colmean:
+            ctx, lse = ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, want_lse=True, kv_shift=B)
+            col = ops.attention_cross_colmean(qkv[:, :hid], lse, B, HEADS, T, scale, lens)
+            return _mlp_tail(x, ctx, p), col[:B], col[B:]
+        return _mlp_tail(x, ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B), p)
     if _half_path() and not want_colmean:
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], half_copy="only")
         qk16, v16 = h16[:, :hid], h16[:, hid:]
@@ -128,8 +154,24 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     return _mlp_tail(x, ctx, p)
 
 
+def with_model_precision(fn):
+    """Run a model method under the model's own ``precision`` (None = the process default, ops.*_precision)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with ops.precision_scope(getattr(self, "precision", None)):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class PackedCache:
-    """Mixin: device-side packed weights, rebuilt after load_state_dict / .to() / .cuda()."""
+    """Mixin: device-side packed weights, rebuilt after load_state_dict / .to() / .cuda(); per-model MFMA path."""
+    precision: Optional[str] = None      # "f32" | "x3" | "f16"; None follows ops.gemm_precision / ops.attention_precision
+
+    def set_precision(self, p: Optional[str]):
+        self.precision = None if p is None else ops._check_precision(p)
+        return self
 
     def _packed_get(self, builder):
         dev = next(self.parameters()).device
@@ -142,8 +184,7 @@ class PackedCache:
         return cache[key]
 
     def _packed_invalidate(self):
-        self.__dict__.setdefault("_packed_store", {}).clear()
-        ops._w16_cache.clear()      # fp16 weight copies are keyed by device address: drop them with their sources
+        self.__dict__.setdefault("_packed_store", {}).clear()      # derived forms (fp16 / split planes) die with the packed tensors
 
     def _apply(self, fn, *a, **k):  # .to/.cuda/.float
         r = super()._apply(fn, *a, **k)

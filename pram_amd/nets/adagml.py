@@ -126,6 +126,7 @@ class AdaGML(GML):
         return ops.linear(h, pp["pr3_w"], pp["pr3_b"])[:, 0].contiguous()
 
     @torch.no_grad()
+    @blk.with_model_precision
     def produce_matches(self, data: dict, p: float = 0.2, **kwargs):
         """Batched, device-resident AdaGML (nets/adagml.py:307-404 per pair).  All nI layers are enqueued;
         per-pair state (token counts, survivor ids, stop flag, the matching descriptors of the layer the

@@ -124,6 +124,7 @@ class GML(blk.PackedCache, nn.Module):
         raise NotImplementedError("training is outside the hot path (nets/gml.py:247 is `pass` in the reference too)")
 
     @torch.no_grad()
+    @blk.with_model_precision
     def produce_matches(self, data: dict, p=0.2, **kwargs):
         desc0, desc1 = data['descriptors0'], data['descriptors1']
         blk.require_cuda(desc0, "GML.produce_matches")

@@ -100,6 +100,7 @@ class SegNetViT(blk.PackedCache, nn.Module):
         return desc0, enc
 
     @torch.no_grad()
+    @blk.with_model_precision
     def forward(self, data: Dict[str, torch.Tensor]):
         desc, (cos, sin) = self.preprocess(data)
         P = self._packed_get(self._build_packed)

@@ -138,6 +138,7 @@ class ResNet4x(blk.PackedCache, nn.Module):
 
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
+    @blk.with_model_precision
     def det(self, x):
         """-> (score [B,H,W], desc [B,128,H/4,W/4]) — nets/sfd2.py:172-199"""
         P, _, _, _, o4 = self._backbone(x)
@@ -145,6 +146,7 @@ class ResNet4x(blk.PackedCache, nn.Module):
         return score, self._nchw_view(self._desc_head(P, o4))
 
     @torch.no_grad()
+    @blk.with_model_precision
     def forward(self, batch):
         """nets/sfd2.py:201-233"""
         P, _, _, _, o4 = self._backbone(batch['image'])
@@ -158,6 +160,7 @@ class ResNet4x(blk.PackedCache, nn.Module):
         return self.forward(batch)
 
     @torch.no_grad()
+    @blk.with_model_precision
     def extract_batched(self, image: torch.Tensor, config: dict, per_image_fallback: bool = True):
         """Device-resident, sync-free form of extract_local_global for batches of independent queries:
         padded keypoints [B,k,2], scores [B,k], descriptors [B,k,128], counts int32 [B] (device)."""
@@ -231,6 +234,7 @@ class DescriptorCompressor(blk.PackedCache, nn.Module):
         self.conv = nn.Conv1d(in_channels=inputdim, out_channels=outdim, kernel_size=1, padding=0, bias=True)
 
     @torch.no_grad()
+    @blk.with_model_precision
     def forward(self, x):
         blk.require_cuda(x, "DescriptorCompressor.forward")
         P = self._packed_get(lambda dev: {"w": self.conv.weight.detach().float().reshape(self.outdim, self.inputdim).contiguous().to(dev),

@@ -37,10 +37,16 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-           rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, half_copy: str = "no"):
+           rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, half_copy: str = "no", split_out: str = "no",
+           precision: Optional[str] = None):
     """out = alpha * ([x | x2] @ w.T + bias) + residual.  x [..., k0] (contiguous rows), w [n, k0+k1].
-    half_copy (fp16 GEMM path only): "also" -> returns (out fp32, out fp16), "only" -> returns (None, out fp16): the
-    fp16 operand of attention_h16."""
+    precision: None = ops.gemm_precision; "f32" exact-fp32 MFMA, "x3" split-fp16 (three fp16 MFMAs per product, fp32-class
+    accuracy), "f16" single fp16 product (BASELINE C5).  Shapes a fast path cannot take (K not a multiple of 32 / 64)
+    run on the exact-fp32 kernel.
+    half_copy (f16 path only): "also" -> returns (out fp32, out fp16), "only" -> returns (None, out fp16): the fp16 operand
+    of attention_h16.
+    split_out (x3 path only): "also" -> (out fp32, (hi, lo)), "only" -> (None, (hi, lo)): the result * 16 as two fp16 planes,
+    the operand format of attention_x3."""
     L = _lib.load()
     x = x.contiguous()
     m, k0 = _rows2d(x, "x")
@@ -53,26 +59,48 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     w = w.contiguous()
     n = w.shape[0]
     assert w.shape[1] == k0 + k1, (w.shape, k0, k1)
-    if out is None:
+    prec = _check_precision(precision or gemm_precision)
+    want32 = not (half_copy == "only" or split_out == "only")
+    if out is None and want32:
         out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
     if residual is not None:
         residual = residual.contiguous()
-    if m == 0:          # empty token set: nothing to launch (an empty tensor has a null data pointer)
-        return out
     flags, rc, rs, rcols = 0, None, None, 0
     if rotary is not None:
         rc, rs, rcols = rotary
         flags = 1
-    use16 = gemm_precision == "f16" and (k0 + k1) % 64 == 0 and (k1 == 0 or k0 % 64 == 0)
+    K = k0 + k1
+    use16 = prec == "f16" and K % 64 == 0 and (k1 == 0 or k0 % 64 == 0)
+    usex3 = prec == "x3" and K % 32 == 0 and (k1 == 0 or k0 % 32 == 0)
     if half_copy != "no":
         if not use16:
-            raise _lib.PramHipError("linear(half_copy=...) needs the fp16 GEMM path (gemm_precision == 'f16', K % 64 == 0)")
+            raise _lib.PramHipError("linear(half_copy=...) needs the fp16 GEMM path (precision 'f16', K % 64 == 0)")
         out16 = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float16)
         o32 = out if half_copy == "also" else None
-        _lib.check(L.pram_linear_f16_h16(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual), n, _p(o32), n,
-                                         _p(out16), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
-                   "pram_linear_f16_h16")
+        if m:
+            _lib.check(L.pram_linear_f16_h16(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual), n, _p(o32), n,
+                                             _p(out16), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+                       "pram_linear_f16_h16")
         return o32, out16
+    if split_out != "no":
+        if not usex3:
+            raise _lib.PramHipError("linear(split_out=...) needs the split-fp16 GEMM path (precision 'x3', K % 32 == 0)")
+        planes = torch.empty(2, *x.shape[:-1], n, device=x.device, dtype=torch.float16)
+        o32 = out if split_out == "also" else None
+        if m:
+            wh, wl, ws = split_weight(w)
+            _lib.check(L.pram_linear_x3_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n,
+                                            _p(o32), n, _p(planes[0]), _p(planes[1]), n, m, n, float(alpha), flags, _p(rc), _p(rs),
+                                            int(rcols), _st()), "pram_linear_x3_f32")
+        return o32, (planes[0], planes[1])
+    if m == 0:          # empty token set: nothing to launch (an empty tensor has a null data pointer)
+        return out
+    if usex3:
+        wh, wl, ws = split_weight(w)
+        _lib.check(L.pram_linear_x3_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n, _p(out), n,
+                                        None, None, 0, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+                   "pram_linear_x3_f32")
+        return out
     if use16:
         _lib.check(L.pram_linear_f16_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual),
                                          n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
@@ -124,23 +152,91 @@ def fourier_encoding(kpts: torch.Tensor, wr: torch.Tensor, cx: float, cy: float,
 # launch stream and (algorithmic flops, start, stop) is appended.  None (default) = no events.
 attention_probe = None
 
-# "f32" (default; exact-fp32 MFMA, the parity path) or "f16" (BASELINE config C5's fp16 MFMA path: fp16 operands,
-# fp32 accumulate / softmax, ~1e-3 relative error).  Set per process via PRAM_ATTENTION_PRECISION or at run time.
+# MFMA path of the three matrix families (token GEMMs + convolutions / attention):
+#   "f32" exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: the f32 vector rate);
+#   "x3"  split-fp16: every fp32 operand = hi + lo in fp16, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate —
+#         fp32-class accuracy (passes the same 1e-3 / indices-exact gates) at 5.3x less matrix time;
+#   "f16" single fp16 product (BASELINE config C5's "fp16 MFMA path", own documented tolerance).
+# Process defaults come from PRAM_PRECISION (both) or PRAM_GEMM_PRECISION / PRAM_ATTENTION_PRECISION; every op also takes
+# an explicit ``precision=`` and every model a ``.precision`` attribute that overrides them.
 import os as _os
-attention_precision = _os.environ.get("PRAM_ATTENTION_PRECISION", "f32")
-# same switch for the token GEMMs and the SFD2 convolutions (fp16 operands, fp32 accumulate / epilogue)
-gemm_precision = _os.environ.get("PRAM_GEMM_PRECISION", "f32")
-_w16_cache = {}
+import weakref as _weakref
+PRECISIONS = ("f32", "x3", "f16")
+default_precision = _os.environ.get("PRAM_PRECISION", "f32")
+attention_precision = _os.environ.get("PRAM_ATTENTION_PRECISION", default_precision)
+gemm_precision = _os.environ.get("PRAM_GEMM_PRECISION", default_precision)
+
+
+def _check_precision(p: str) -> str:
+    if p not in PRECISIONS:
+        raise _lib.PramHipError(f"unknown precision {p!r} (expected one of {PRECISIONS})")
+    return p
+
+
+def set_precision(p: str) -> None:
+    """Process-wide default for both the GEMM / convolution family and the attention family."""
+    global attention_precision, gemm_precision
+    attention_precision = gemm_precision = _check_precision(p)
+
+
+def current_precision() -> str:
+    return attention_precision if attention_precision == gemm_precision else f"gemm {gemm_precision} / attention {attention_precision}"
+
+
+class precision_scope:
+    """``with ops.precision_scope("x3"): ...`` — what a model with a ``.precision`` attribute wraps its forward in."""
+
+    def __init__(self, p: Optional[str]):
+        self.p = p
+
+    def __enter__(self):
+        global attention_precision, gemm_precision
+        self.saved = (attention_precision, gemm_precision)
+        if self.p is not None:
+            attention_precision = gemm_precision = _check_precision(self.p)
+
+    def __exit__(self, *exc):
+        global attention_precision, gemm_precision
+        attention_precision, gemm_precision = self.saved
+        return False
+
+
+# Derived forms of a (static) weight tensor — its fp16 copy, its split planes — live exactly as long as the tensor object
+# they were derived from and are rebuilt when it is modified in place (tensor._version), never keyed by a device address
+# that the allocator may hand to another tensor.
+_derived_cache = {}
+
+
+def _derived(w: torch.Tensor, kind: str, fn):
+    ent = _derived_cache.get(id(w))
+    if ent is None or ent[0]() is not w or ent[1] != w._version:
+        key = id(w)
+        ent = (_weakref.ref(w, lambda _r, k=key: _derived_cache.pop(k, None)), w._version, {})
+        _derived_cache[key] = ent
+    v = ent[2].get(kind)
+    if v is None:
+        with torch.no_grad():
+            v = ent[2][kind] = fn(w)
+    return v
 
 
 def _w16(w: torch.Tensor) -> torch.Tensor:
-    """fp16 copy of a (static) weight tensor, converted once per device buffer."""
-    key = (w.data_ptr(), tuple(w.shape))
-    h = _w16_cache.get(key)
-    if h is None:
-        h = w.half().contiguous()
-        _w16_cache[key] = h
-    return h
+    """fp16 copy of a (static) weight tensor."""
+    return _derived(w, "h16", lambda t: t.half().contiguous())
+
+
+def split_weight(w: torch.Tensor):
+    """-> (hi, lo, scale): w * scale = hi + lo as two fp16 tensors of w's shape; scale = the power of two that puts
+    max|w| into [2^13, 2^14) (exact to apply and to undo), so hi + lo carries 22 bits of every weight above 2^-17 max|w|."""
+    def make(t):
+        amax = float(t.abs().max())
+        import math
+        scale = 2.0 ** math.floor(math.log2(16384.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+        ts = t.float() * scale
+        hi = ts.half()
+        lo = (ts - hi.float()).half()
+        return hi.contiguous(), lo.contiguous(), float(scale)
+    return _derived(w, "x3", make)
 
 
 attention_split = True      # False: never hand the kernel a split workspace (tests compare both modes bit for bit)
@@ -169,9 +265,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    prec = precision or attention_precision
-    if prec not in ("f32", "f16"):
-        raise _lib.PramHipError(f"unknown attention precision {prec!r}")
+    prec = _check_precision(precision or attention_precision)
+    if prec == "x3":
+        prec = "f32"      # fp32 operands in HBM: the split path starts at the projection (attention_x3 takes its planes)
     if prec == "f32":
         ws, nb = _attention_ws(L, batch, heads, m_max, n_max, q.device)
         rc = L.pram_attention_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
@@ -223,6 +319,33 @@ def attention_h16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int,
     return (out, lse) if want_lse else out
 
 
+def attention_x3(q, k, v, batch: int, heads: int, m_max: int, n_max: int, scale: float,
+                 q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None, want_lse: bool = False,
+                 out: Optional[torch.Tensor] = None, kv_shift: int = 0):
+    """Split-fp16 flash attention.  q / k / v: (hi, lo) pairs of fp16 2-D views (column slices of the planes written by
+    linear(split_out=...)): fp32-class results, three fp16 MFMAs per product.  kv_shift: see attention_cross."""
+    L = _lib.load()
+    for pair in (q, k, v):
+        for t in pair:
+            assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
+        assert pair[0].stride(0) == pair[1].stride(0)
+    if out is None:
+        out = torch.empty(batch * m_max, heads * 64, device=q[0].device, dtype=torch.float32)
+    lse = torch.empty(batch, heads, m_max, device=q[0].device, dtype=torch.float32) if want_lse else None
+    probe = attention_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(L.pram_attention_x3_f32(_p(q[0]), _p(q[1]), q[0].stride(0), _p(k[0]), _p(k[1]), k[0].stride(0), _p(v[0]), _p(v[1]),
+                                       v[0].stride(0), _p(out), out.stride(0), _p(lse), _p(q_lens), _p(k_lens), batch, heads,
+                                       m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_x3_f32")
+    if probe is not None:
+        e1.record()
+        kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
+        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1))
+    return (out, lse) if want_lse else out
+
+
 def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t_max: int, scale: float,
                     lens: Optional[torch.Tensor] = None, want_lse: bool = False, out: Optional[torch.Tensor] = None,
                     precision: Optional[str] = None):
@@ -241,9 +364,9 @@ def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    prec = precision or attention_precision
-    if prec not in ("f32", "f16"):
-        raise _lib.PramHipError(f"unknown attention precision {prec!r}")
+    prec = _check_precision(precision or attention_precision)
+    if prec == "x3":
+        prec = "f32"
     if prec == "f32":
         ws, nb = _attention_ws(L, S, heads, t_max, t_max, qk.device)
         rc = L.pram_attention_cross_f32(_p(qk), qk.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), _p(lse), _p(lens),
@@ -269,17 +392,49 @@ def attention_cross_colmean(qk: torch.Tensor, lse2: torch.Tensor, pairs: int, he
 
 
 _ws_cache = {}
+_ws_scopes = []          # innermost active workspace_scope store
+_ws_captured = []        # scratch allocated while a stream was capturing outside any scope: owned by the process
+
+
+class workspace_scope:
+    """Route every scratch allocation of the enclosed launches into ``store`` (a dict owned by the caller) instead of
+    the process-wide cache.  ``GraphedPipeline`` warms up and captures inside its own scope, so the pointers baked into
+    its hipGraph belong to that graph alone: a later eager run that needs a larger workspace, or a second graph
+    captured on torch's shared capture stream, can neither free nor share them.  A buffer that has to grow inside a
+    scope is retired, not freed (an earlier capture may still point at it)."""
+
+    def __init__(self, store: dict):
+        self.store = store
+
+    def __enter__(self):
+        _ws_scopes.append(self.store)
+        return self.store
+
+    def __exit__(self, *exc):
+        _ws_scopes.pop()
+        return False
 
 
 def _workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
     """Scratch memory owned by (device, purpose, stream): launches on different streams never share a workspace, so
-    several batches can be in flight at once."""
+    several batches can be in flight at once.  See workspace_scope for hipGraph capture."""
     key = (str(device), tag, _st())
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
-        _ws_cache[key] = ws
-    return ws
+    scoped = bool(_ws_scopes)
+    store = _ws_scopes[-1] if scoped else _ws_cache
+    ws = store.get(key)
+    if ws is not None and ws.numel() >= nbytes:
+        return ws
+    new = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+    if scoped:
+        if ws is not None:
+            store.setdefault("_retired", []).append(ws)
+        store[key] = new
+    elif torch.cuda.is_current_stream_capturing():
+        # captured outside a scope: never enters (or evicts from) the eager cache, and is never freed
+        _ws_captured.append(new)
+    else:
+        store[key] = new
+    return new
 
 
 def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, threshold: float,
@@ -338,8 +493,9 @@ def adagml_scatter(matches0, mscores0, ind0, ind1, lens0, m_full):
 
 # ------------------------------------------------------------------------------------- SFD2
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=None, residual=None, ks: int = 3,
-                stride: int = 1, relu: bool = False) -> torch.Tensor:
-    """x [B,H,W,Cin] contiguous NHWC; w [Cout,ks,ks,Cin]."""
+                stride: int = 1, relu: bool = False, precision: Optional[str] = None) -> torch.Tensor:
+    """x [B,H,W,Cin] contiguous NHWC; w [Cout,ks,ks,Cin].  precision: see linear() (conv1a's 4-channel input always runs
+    on the exact-fp32 kernel)."""
     L = _lib.load()
     _chk(x, "x")
     assert x.is_contiguous() and w.is_contiguous()
@@ -348,7 +504,13 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=N
     pad = ks // 2
     Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
     out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    if gemm_precision == "f16" and Cin % 64 == 0:
+    prec = _check_precision(precision or gemm_precision)
+    if prec == "x3" and Cin % 32 == 0:
+        wh, wl, ws = split_weight(w)
+        _lib.check(L.pram_conv2d_nhwc_x3_f32(_p(x), B, H, W, Cin, _p(wh), _p(wl), ws, _p(bias), _p(scale), _p(shift), _p(residual),
+                                             _p(out), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_x3_f32")
+        return out
+    if prec == "f16" and Cin % 64 == 0:
         _lib.check(L.pram_conv2d_nhwc_f16_f32(_p(x), B, H, W, Cin, _p(_w16(w)), _p(bias), _p(scale), _p(shift), _p(residual),
                                               _p(out), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f16_f32")
         return out

@@ -96,15 +96,38 @@ class QueryPipeline:
         return rec
 
 
-def gather_records(rec: torch.Tensor) -> torch.Tensor:
-    """One all-gather of the result records over RCCL/xGMI (backend 'nccl' on ROCm; gloo on CPU tests)."""
+def gather_records(rec: torch.Tensor, shard_sizes=None) -> torch.Tensor:
+    """One all-gather of the result records over RCCL/xGMI (backend 'nccl' on ROCm; gloo on CPU tests).
+
+    ``shard_sizes`` = queries held by every rank, in rank order (what ``shard_range`` gives each rank — known on every
+    rank without communication).  Uneven shards (65 queries over 8 GPUs) are padded to the largest shard for the
+    collective and trimmed afterwards, so the result is the [sum(shard_sizes), ...] record array in query order; with
+    ``shard_sizes=None`` all ranks must hold the same number of queries."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rec
     ws = dist.get_world_size()
-    full = torch.empty((ws * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
-    dist.all_gather_into_tensor(full, rec.contiguous())
-    return full
+    tail = tuple(rec.shape[1:])
+    if shard_sizes is None:
+        full = torch.empty((ws * rec.shape[0],) + tail, device=rec.device, dtype=rec.dtype)
+        dist.all_gather_into_tensor(full, rec.contiguous())
+        return full
+    sizes = [int(x) for x in shard_sizes]
+    if len(sizes) != ws or sizes[dist.get_rank()] != rec.shape[0]:
+        raise ValueError(f"shard_sizes {sizes} do not describe this job (world {ws}, this rank holds {rec.shape[0]})")
+    big = max(sizes)
+    if big == 0:
+        return rec
+    mine = rec.contiguous()
+    if rec.shape[0] < big:
+        mine = torch.zeros((big,) + tail, device=rec.device, dtype=rec.dtype)
+        mine[:rec.shape[0]] = rec
+    full = torch.empty((ws * big,) + tail, device=rec.device, dtype=rec.dtype)
+    dist.all_gather_into_tensor(full, mine)
+    if min(sizes) == big:
+        return full
+    full = full.view((ws, big) + tail)
+    return torch.cat([full[r, :sizes[r]] for r in range(ws)], 0)
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -129,21 +152,38 @@ class GraphedPipeline:
         self.pipe, self.stages = pipe, stages
         self.images = images.clone()
         self.ref = None if ref is None else {k: v.clone() for k, v in ref.items()}
+        self._ws = {}                 # this graph's private scratch (ops.workspace_scope): never shared, never regrown by others
+        self._side = torch.cuda.Stream(device=images.device) if pipe.overlap_below > images.shape[0] else None
         side = torch.cuda.Stream(device=images.device)
         side.wait_stream(torch.cuda.current_stream(images.device))
-        with torch.cuda.stream(side):                    # warm up off the default stream: packs weights, sizes workspaces
-            for _ in range(warmup):
-                pipe.run(self.images, self.ref, stages)
-        torch.cuda.current_stream(images.device).wait_stream(side)
-        torch.cuda.synchronize(images.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = pipe.run(self.images, self.ref, stages)
+        with ops.workspace_scope(self._ws):
+            with torch.cuda.stream(side):                # warm up off the default stream: packs weights, sizes workspaces
+                for _ in range(warmup):
+                    self._run_eager()
+            torch.cuda.current_stream(images.device).wait_stream(side)
+            torch.cuda.synchronize(images.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._run_eager()
+
+    def _run_eager(self):
+        # the forked branch runs on a side stream owned by THIS graph (the pipeline's own side stream keeps serving eager runs)
+        saved, self.pipe._side = self.pipe._side, self._side
+        try:
+            return self.pipe.run(self.images, self.ref, self.stages)
+        finally:
+            self._side, self.pipe._side = self.pipe._side, saved
 
     @torch.no_grad()
     def run(self, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         if tuple(images.shape) != tuple(self.images.shape):
             raise ValueError(f"graph was captured for images {tuple(self.images.shape)}, got {tuple(images.shape)}")
+        if ref is not None:
+            if self.ref is None:
+                raise ValueError("this graph was captured without reference sets (ref=None): it has no matcher stage to feed")
+            for k, v in ref.items():
+                if k not in self.ref or tuple(self.ref[k].shape) != tuple(v.shape):
+                    raise ValueError(f"ref[{k!r}]: captured {tuple(self.ref[k].shape) if k in self.ref else None}, got {tuple(v.shape)}")
         self.images.copy_(images)
         if ref is not None:
             for k, v in ref.items():

@@ -205,3 +205,23 @@ def synthetic_match_pair(index: int, m: int = 2048, n: int = 2048, dim: int = 12
     gt[perm[:inl]] = torch.arange(inl)
     return dict(descriptors0=d0, keypoints0=k0, scores0=s0,
                 descriptors1=d1, keypoints1=k1, scores1=s1, gt=gt)
+
+
+def calibrate_matcher_input(sd: Dict[str, torch.Tensor], descriptors: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Matcher weights whose input projection is calibrated to a descriptor population (bench.py / full-pipeline tests).
+
+    With random (untrained) weights SFD2's descriptors share one dominant direction (mean pairwise cosine ~0.96 on the
+    synthetic frames), so an untrained matcher sees 2048 nearly identical tokens and nothing clears the match threshold —
+    a degenerate workload whose result record cannot be sanity-checked.  A trained matcher has absorbed its extractor's
+    statistics; the synthetic equivalent is one affine re-parametrisation of ``input_proj``:
+        input_proj'(d) = W g (d - mu) + b ,   mu = mean descriptor,  g = 1 / mean ||d - mu||
+    (weights W' = g W, bias b' = b - g W mu).  Same architecture, same arithmetic per query; only the synthetic
+    parameter values change, identically for the HIP path and the oracle that checks it."""
+    d = descriptors.detach().reshape(-1, descriptors.shape[-1]).double().cpu()
+    mu = d.mean(0)
+    g = 1.0 / float((d - mu).norm(dim=1).mean().clamp_min(1e-6))
+    out = dict(sd)
+    w = sd["input_proj.weight"].double() * g
+    out["input_proj.weight"] = w.float()
+    out["input_proj.bias"] = (sd["input_proj.bias"].double() - w @ mu).float()
+    return out

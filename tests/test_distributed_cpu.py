@@ -25,8 +25,10 @@ def _worker(rank, world, port, n_queries, q):
     try:
         lo, hi = shard_range(n_queries, rank, world)
         # a rank's record depends only on its own query ids (embarrassingly parallel)
-        rec = torch.stack([torch.full((4, 6), float(i)) + torch.arange(6.0) for i in range(lo, hi)])
-        full = gather_records(rec)
+        rec = (torch.stack([torch.full((4, 6), float(i)) + torch.arange(6.0) for i in range(lo, hi)]) if hi > lo
+               else torch.zeros(0, 4, 6))
+        sizes = [b - a for a, b in (shard_range(n_queries, r, world) for r in range(world))]
+        full = gather_records(rec, sizes if min(sizes) != max(sizes) else None)
         want = torch.stack([torch.full((4, 6), float(i)) + torch.arange(6.0) for i in range(n_queries)])
         q.put((rank, bool(torch.equal(full, want)), tuple(full.shape)))
     finally:
@@ -43,8 +45,13 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_gather_records_world2():
-    world, n = 2, 6
+import pytest
+
+
+@pytest.mark.parametrize("n", [6, 7, 1])
+def test_gather_records_world2(n):
+    """even shards (3 + 3), uneven (4 + 3) and a rank without queries (1 + 0): always the n records in query order"""
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -27,7 +27,8 @@ def test_bench_one_gpu_line(hip_lib):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["dtype"].startswith("f32") and d["vs_baseline"] is None
+    assert d["parity"]["ok"] and d["parity"]["match"]["indices_identical"] and d["config"]["matches_last_step"] > 0
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 0.05 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches_per_step"] == 33
@@ -37,9 +38,32 @@ def test_bench_two_ranks_control_flow(hip_lib):
     env = dict(os.environ, PRAM_BENCH_ONE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29517", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch-per-gpu", "2", "--cpu-queries", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--batch-per-gpu", "2", "--cpu-queries", "0", "--no-parity"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     # whole-job aggregate: both ranks' queries over the max-over-ranks time
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 0.05 * d["value"]
+
+
+def test_bench_spawns_its_own_ranks_and_shards_unevenly(hip_lib):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (one-GPU test hook: both on GPU 0 over gloo) and
+    reports n_gpus = 2; --batch-total 3 gives the ranks 2 + 1 queries (uneven shards through the padded all-gather)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PRAM_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-total", "3",
+                        "--cpu-queries", "0", "--no-parity"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["queries_per_step"] == 3
+    assert d["config"]["queries_per_gpu_per_step"] == [2, 1]
+    assert abs(d["value"] - 3 * 2 / (d["ms_per_step"] * 2e-3)) < 0.05 * d["value"]
+
+
+def test_bench_refuses_more_gpus_than_visible(hip_lib):
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PRAM_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
