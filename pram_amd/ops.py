@@ -162,7 +162,7 @@ attention_probe = None
 import os as _os
 import weakref as _weakref
 PRECISIONS = ("f32", "x3", "f16")
-default_precision = _os.environ.get("PRAM_PRECISION", "f32")
+default_precision = _os.environ.get("PRAM_PRECISION", "x3")
 attention_precision = _os.environ.get("PRAM_ATTENTION_PRECISION", default_precision)
 gemm_precision = _os.environ.get("PRAM_GEMM_PRECISION", default_precision)
 

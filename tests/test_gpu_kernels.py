@@ -88,8 +88,10 @@ def test_linear_mfma_layout_asymmetric(dev):
     m = n = k = 128
     x = torch.eye(m, k)
     w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251) / 7.0
-    out = ops.linear(x.to(dev), w.to(dev))
-    assert torch.equal(out.cpu(), w.t().contiguous())
+    out = ops.linear(x.to(dev), w.to(dev), precision="f32")
+    assert torch.equal(out.cpu(), w.t().contiguous())          # exact-fp32 MFMA: 1.0 * w is w
+    out3 = ops.linear(x.to(dev), w.to(dev), precision="x3")
+    assert float(((out3.cpu() - w.t()).abs() / w.t().clamp_min(1.0)).max()) <= 2.0 ** -21      # split-fp16: w to 22 bits
 
 
 def test_qkv_rotary_epilogue(dev):
