@@ -136,14 +136,22 @@ int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, c
                            int m_max, int n_max, float scale, int kv_shift, void* stream);
 
 /* Split-fp16 ("x3") flash attention — the default attention of the fp32 parity path (same einsum -> softmax -> einsum
- * sites as pram_attention_f32).  q / k / v are the split planes written by pram_linear_x3_f32 (value * 16 = hi + lo,
- * ld* in halves, multiples of 8; heads are 64-wide column blocks); S = K Q^T and O = P V are three fp16 MFMAs per
- * product with fp32 accumulation, the probabilities are split in registers.  Output fp32.  kv_shift as in
- * pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs). */
+ * sites as pram_attention_f32).  q / k are row-major split planes written by pram_linear_x3_f32 (value * 16 = hi + lo,
+ * ld* in halves, multiples of 8; heads are 64-wide column blocks); vt_hi / vt_lo are the TRANSPOSED value planes of the
+ * key side built by pram_attention_x3_vt: [batch][heads][64][tv], tv = n_max rounded up to 64.  S = K Q^T and O = P V are
+ * three fp16 MFMAs per product with fp32 accumulation, the probabilities are split in registers.  Output fp32.
+ * kv_shift as in pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs). */
 int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
-                          const void* v_hi, const void* v_lo, int ldv, float* out, int ldo, float* lse2,
+                          const void* vt_hi, const void* vt_lo, float* out, int ldo, float* lse2,
                           const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
                           float scale, int kv_shift, void* stream);
+
+/* Row-major value planes [seqs * t_max][ldv] (head h at columns 64 h ..) -> the transposed, key-permuted planes
+ * pram_attention_x3_f32 stages with plain 16-byte copies: [seqs][heads][64][tv], tv = t_max rounded up to 64, position of
+ * token t = 64 (t / 64) + perm(t % 64) (the order in which the S^T accumulator registers hold the keys); tokens
+ * t >= lens[seq] (NULL: t_max) are written as zeros. */
+int pram_attention_x3_vt(const void* v_hi, const void* v_lo, int ldv, void* vt_hi, void* vt_lo, const int* lens,
+                         int seqs, int heads, int t_max, void* stream);
 
 /* Both directions of CrossMultiHeadAttention.forward (nets/gml.py:175-179; adagml.py:222-231) in ONE launch:
  * 2*pairs sequences of t_max rows each, sequences 0..pairs-1 = set 0, pairs..2*pairs-1 = set 1; sequence s takes

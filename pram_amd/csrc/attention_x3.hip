@@ -28,10 +28,11 @@ constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3
 constexpr float P_EXP_SHIFT = 14.0f;    // probabilities carried as 2^14 p
 
 struct ArgsX {
-    const _Float16* qh; const _Float16* ql; const _Float16* kh; const _Float16* kl; const _Float16* vh; const _Float16* vl;
+    const _Float16* qh; const _Float16* ql; const _Float16* kh; const _Float16* kl;
+    const _Float16* vh; const _Float16* vl;   // V^T planes [batch][heads][64][tv] with the key permutation of pos_of_key (vt_kernel)
     float* out; float* lse2;
     const int* q_lens; const int* k_lens;
-    int ldq, ldk, ldv, ldo;          // ldq / ldk / ldv in halves
+    int ldq, ldk, tv, ldo;           // ldq / ldk in halves; tv = padded key count of a V^T row (multiple of 64)
     int batch, heads, m_max, n_max;
     float scale2;                    // scale * log2(e) / IN_SCALE^2
     int q_tiles;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
 
     const size_t qoff = ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
     const size_t koff = (size_t)kb * p.n_max * p.ldk + head * D;
-    const size_t voff = (size_t)kb * p.n_max * p.ldv + head * D;
+    const size_t voff = ((size_t)kb * p.heads + head) * D * p.tv;
 
     // Q fragments: q?[c][i] = plane(Q[qrow][16c + 8h + i])
     half8 qh[4], ql[4];
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             for (int i = 0; i < 8; ++i) { qh[c][i] = (_Float16)0.f; ql[c][i] = (_Float16)0.f; }
     }
 
-    const int lrow = tid >> 3, lseg = tid & 7;      // staging: key lrow + 32p, halves 8*lseg .. 8*lseg+7
+    // staging: K rows are keys (halves 8*lseg .. +7 of key lrow + 32p); V^T rows are head dims (positions 8*lseg .. +7 of
+    // dim lrow + 32p): both are plain 16-byte copies.  Keys beyond klen: the K row is a duplicate of the last valid key
+    // (its scores are masked to -inf), the V^T positions hold zeros (vt_kernel), so P = 0 meets a finite value.
+    const int lrow = tid >> 3, lseg = tid & 7;
     half8 krh[2], krl[2], vrh[2], vrl[2];
     auto gload = [&](int kt) {
 #pragma unroll
@@ -104,36 +108,26 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             const size_t kc = (size_t)min(kt * BKV + lrow + 32 * pp, klen - 1);
             krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
             krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
-            vrh[pp] = *reinterpret_cast<const half8*>(p.vh + voff + kc * p.ldv + lseg * 8);
-            vrl[pp] = *reinterpret_cast<const half8*>(p.vl + voff + kc * p.ldv + lseg * 8);
+            const size_t vo = voff + (size_t)(lrow + 32 * pp) * p.tv + kt * BKV + lseg * 8;
+            vrh[pp] = *reinterpret_cast<const half8*>(p.vh + vo);
+            vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
         }
     };
-    auto lstore = [&](int buf, int kt) {
+    auto lstore = [&](int buf) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int row = lrow + 32 * pp;
-            const bool ok = kt * BKV + row < klen;
-            half8 a = krh[pp], bq = krl[pp], c = vrh[pp], d8 = vrl[pp];
-            if (!ok)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { a[i] = (_Float16)0.f; bq[i] = (_Float16)0.f; c[i] = (_Float16)0.f; d8[i] = (_Float16)0.f; }
-            const int koffs = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
-            *reinterpret_cast<half8*>(&s.kh[buf][koffs]) = a;
-            *reinterpret_cast<half8*>(&s.kl[buf][koffs]) = bq;
-            const int pos = pos_of_key(row);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = lseg * 8 + j;
-                const int vo = d * BKV + (((pos >> 3) ^ ((d >> 1) & 7)) << 3) + (pos & 7);
-                s.vth[buf][vo] = c[j];
-                s.vtl[buf][vo] = d8[j];
-            }
+            const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);      // K [key][d] and V^T [d][pos]: same 128-B rows, same swizzle
+            *reinterpret_cast<half8*>(&s.kh[buf][off]) = krh[pp];
+            *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
+            *reinterpret_cast<half8*>(&s.vth[buf][off]) = vrh[pp];
+            *reinterpret_cast<half8*>(&s.vtl[buf][off]) = vrl[pp];
         }
     };
 
     const int nkt = (klen + BKV - 1) / BKV;
     gload(0);
-    lstore(0, 0);
+    lstore(0);
     __syncthreads();
 
     float m_run = -1.0e30f, l_run = 0.f;
@@ -150,20 +144,49 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             f32x16 st[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            // K fragments of step c + 1 are requested before the MFMAs of step c (pinned with sched_barrier: hipcc otherwise
+            // sinks each ds_read next to its first use and every MFMA group starts with an exposed LDS round trip)
+            struct KFrag { half8 h0, h1, l0, l1; };
+            auto kload = [&](int c, KFrag& f) {
                 const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;   // ((32 + r) >> 1) & 7 == (r >> 1) & 7
-                const half8 k0h = *reinterpret_cast<const half8*>(&s.kh[cur][r * D + slot]);
-                const half8 k1h = *reinterpret_cast<const half8*>(&s.kh[cur][(32 + r) * D + slot]);
-                const half8 k0l = *reinterpret_cast<const half8*>(&s.kl[cur][r * D + slot]);
-                const half8 k1l = *reinterpret_cast<const half8*>(&s.kl[cur][(32 + r) * D + slot]);
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0l, qh[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1l, qh[c], st[1], 0, 0, 0);
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, ql[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, ql[c], st[1], 0, 0, 0);
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, qh[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, qh[c], st[1], 0, 0, 0);
-            }
+                f.h0 = *reinterpret_cast<const half8*>(&s.kh[cur][r * D + slot]);
+                f.h1 = *reinterpret_cast<const half8*>(&s.kh[cur][(32 + r) * D + slot]);
+                f.l0 = *reinterpret_cast<const half8*>(&s.kl[cur][r * D + slot]);
+                f.l1 = *reinterpret_cast<const half8*>(&s.kl[cur][(32 + r) * D + slot]);
+            };
+            auto kmma = [&](int c, const KFrag& f) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, qh[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, qh[c], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ql[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ql[c], st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, qh[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, qh[c], st[1], 0, 0, 0);
+            };
+            KFrag ka, kb2;
+            kload(0, ka);
+            kload(1, kb2);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(0, ka);
+            kload(2, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(1, kb2);
+            kload(3, kb2);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(2, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(3, kb2);
+            // the V^T fragments of the first two PV steps travel under the softmax arithmetic
+            struct VFrag { half8 h0, h1, l0, l1; };
+            auto vload = [&](int t, int u, VFrag& f) {
+                const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
+                f.h0 = *reinterpret_cast<const half8*>(&s.vth[cur][r * BKV + slot]);
+                f.h1 = *reinterpret_cast<const half8*>(&s.vth[cur][(32 + r) * BKV + slot]);
+                f.l0 = *reinterpret_cast<const half8*>(&s.vtl[cur][r * BKV + slot]);
+                f.l1 = *reinterpret_cast<const half8*>(&s.vtl[cur][(32 + r) * BKV + slot]);
+            };
+            VFrag va, vb;
+            vload(0, 0, va);
+            vload(0, 1, vb);
             if (!more && (klen & (BKV - 1))) {
                 const int kbase = kt * BKV;
 #pragma unroll
@@ -197,24 +220,26 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             m_run = m_new;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
-                    const half8 v0h = *reinterpret_cast<const half8*>(&s.vth[cur][r * BKV + slot]);
-                    const half8 v1h = *reinterpret_cast<const half8*>(&s.vth[cur][(32 + r) * BKV + slot]);
-                    const half8 v0l = *reinterpret_cast<const half8*>(&s.vtl[cur][r * BKV + slot]);
-                    const half8 v1l = *reinterpret_cast<const half8*>(&s.vtl[cur][(32 + r) * BKV + slot]);
-                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph[t][u], oacc[0], 0, 0, 0);
-                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph[t][u], oacc[1], 0, 0, 0);
-                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl[t][u], oacc[0], 0, 0, 0);
-                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl[t][u], oacc[1], 0, 0, 0);
-                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph[t][u], oacc[0], 0, 0, 0);
-                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph[t][u], oacc[1], 0, 0, 0);
-                }
+            auto vmma = [&](int t, int u, const VFrag& f) {
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ph[t][u], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ph[t][u], oacc[1], 0, 0, 0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            vmma(0, 0, va);
+            vload(1, 0, va);
+            __builtin_amdgcn_sched_barrier(0);
+            vmma(0, 1, vb);
+            vload(1, 1, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            vmma(1, 0, va);
+            __builtin_amdgcn_sched_barrier(0);
+            vmma(1, 1, vb);
         }
-        if (more) lstore(cur ^ 1, kt + 1);
+        if (more) lstore(cur ^ 1);
         __syncthreads();
     }
 
@@ -235,22 +260,80 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
     }
 }
 
+// V^T planes for attention_x3_kernel: [seq][head][64 dims][tv positions] fp16, position = 64 * (t / 64) + pos_of_key(t % 64),
+// zeros for t >= lens[seq] (a masked key then meets a finite value).  One workgroup = 64 tokens of one (sequence, head):
+// 16-byte reads along d, a 64 x 64 transpose through LDS, 16-byte writes along the positions.
+struct VtArgs {
+    const _Float16* vh; const _Float16* vl; int ldv;      // row-major value planes [seq * t_max][ldv], head h at columns 64 h ..
+    _Float16* oh; _Float16* ol;
+    const int* lens;
+    int t_max, tv, heads;
+};
+
+__global__ __launch_bounds__(256) void vt_kernel(VtArgs p) {
+    __shared__ _Float16 sh[2][64][72];      // [plane][d][pos], rows padded to 144 B: the transposing 2-byte writes spread over the banks
+    const int blk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+    const int len = p.lens ? min(p.lens[seq], p.t_max) : p.t_max;
+    const int tid = threadIdx.x;
+    const int key = tid >> 2, seg = tid & 3;                 // token blk*64 + key, dims 16 seg .. 16 seg + 15
+    const int t = blk * 64 + key;
+    const int pos = pos_of_key(key);
+    half8 a0, a1, b0, b1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a0[i] = (_Float16)0.f; a1[i] = a0[i]; b0[i] = a0[i]; b1[i] = a0[i]; }
+    if (t < len) {
+        const size_t src = ((size_t)seq * p.t_max + t) * p.ldv + head * D + seg * 16;
+        a0 = *reinterpret_cast<const half8*>(p.vh + src);
+        a1 = *reinterpret_cast<const half8*>(p.vh + src + 8);
+        b0 = *reinterpret_cast<const half8*>(p.vl + src);
+        b1 = *reinterpret_cast<const half8*>(p.vl + src + 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sh[0][seg * 16 + i][pos] = a0[i];
+        sh[0][seg * 16 + 8 + i][pos] = a1[i];
+        sh[1][seg * 16 + i][pos] = b0[i];
+        sh[1][seg * 16 + 8 + i][pos] = b1[i];
+    }
+    __syncthreads();
+    const int d = tid >> 2, part = tid & 3;                  // dim d, positions 16 part .. 16 part + 15
+    const size_t dst = (((size_t)seq * p.heads + head) * D + d) * p.tv + blk * 64 + part * 16;
+    *reinterpret_cast<half8*>(p.oh + dst) = *reinterpret_cast<const half8*>(&sh[0][d][part * 16]);
+    *reinterpret_cast<half8*>(p.oh + dst + 8) = *reinterpret_cast<const half8*>(&sh[0][d][part * 16 + 8]);
+    *reinterpret_cast<half8*>(p.ol + dst) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16]);
+    *reinterpret_cast<half8*>(p.ol + dst + 8) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16 + 8]);
+}
+
 }  // namespace
 
-/* Split-fp16 q / k / v planes in HBM (written by pram_linear_x3_f32: value * 16 = hi + lo): ld* in halves, 16-byte aligned
-   rows and head offsets.  kv_shift > 0: keys / values of sequence s come from sequence (s + kv_shift) % batch (cross
+/* Value planes [seqs * t_max][ldv] (head h at columns 64 h .., as pram_linear_x3_f32 writes them) -> transposed, key-permuted
+   planes [seqs][heads][64][tv], tv = t_max rounded up to a multiple of 64; tokens t >= lens[seq] (NULL = t_max) become zeros. */
+extern "C" int pram_attention_x3_vt(const void* v_hi, const void* v_lo, int ldv, void* vt_hi, void* vt_lo, const int* lens,
+                                    int seqs, int heads, int t_max, void* stream) {
+    PRAM_REQUIRE(v_hi && v_lo && vt_hi && vt_lo, "pram_attention_x3_vt: null pointer");
+    PRAM_REQUIRE(ldv % 8 == 0 && heads > 0 && seqs >= 0 && t_max >= 0, "pram_attention_x3_vt: bad sizes");
+    if (seqs == 0 || t_max == 0) return PRAM_OK;
+    const int tv = cdiv(t_max, 64) * 64;
+    VtArgs p{(const _Float16*)v_hi, (const _Float16*)v_lo, ldv, (_Float16*)vt_hi, (_Float16*)vt_lo, lens, t_max, tv, heads};
+    hipLaunchKernelGGL(vt_kernel, dim3(tv / 64, heads, seqs), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_x3_vt");
+}
+
+/* Split-fp16 flash attention.  q / k: row-major planes written by pram_linear_x3_f32 (value * 16 = hi + lo; ld* in halves,
+   16-byte aligned rows and head offsets); vt: the V^T planes of pram_attention_x3_vt for the KEY side ([batch][heads][64][tv],
+   tv = n_max rounded up to 64).  kv_shift > 0: keys / values of sequence s come from sequence (s + kv_shift) % batch (cross
    attention, both directions in one launch). */
 extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
-                                     const void* v_hi, const void* v_lo, int ldv, float* out, int ldo, float* lse2,
+                                     const void* vt_hi, const void* vt_lo, float* out, int ldo, float* lse2,
                                      const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
                                      float scale, int kv_shift, void* stream) {
-    PRAM_REQUIRE(q_hi && q_lo && k_hi && k_lo && v_hi && v_lo && out, "pram_attention_x3_f32: null pointer");
-    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "pram_attention_x3_f32: ld of the fp16 planes must be a multiple of 8");
+    PRAM_REQUIRE(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out, "pram_attention_x3_f32: null pointer");
+    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "pram_attention_x3_f32: ld of the fp16 planes must be a multiple of 8");
     PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_x3_f32: bad sizes");
     if (batch == 0 || m_max == 0) return PRAM_OK;
     PRAM_REQUIRE(n_max > 0, "pram_attention_x3_f32: empty key set");
-    ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)v_hi,
-            (const _Float16*)v_lo, out, lse2, q_lens, k_lens, ldq, ldk, ldv, ldo, batch, heads, m_max, n_max,
+    ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
+            (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
             scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift};
     hipLaunchKernelGGL(attention_x3_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_x3_f32");

@@ -82,22 +82,27 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    float4 ra[C::PA];
-    uint4 rbh[C::PB], rbl[C::PB];
-    unsigned ok = 0u;
-    auto issue = [&](int kt) {
-        ok = 0u;
-#pragma unroll
-        for (int p = 0; p < C::PA; ++p) { ra[p] = la(p, kt); ok |= (oka(p, kt) ? 1u : 0u) << p; }
-#pragma unroll
-        for (int p = 0; p < C::PB; ++p) { rbh[p] = lb(p, kt, 0); rbl[p] = lb(p, kt, 1); ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+    // Two chunks of global loads are in flight: a chunk is only 24 MFMAs = 768 matrix cycles per wave, far less than a
+    // global-load round trip under load, so chunk kt + 2 is requested (into the register set chunk kt has just left)
+    // before chunk kt is multiplied, and chunk kt + 1 — requested one iteration earlier — is split and written to LDS after.
+    struct Regs {
+        float4 a[C::PA];
+        uint4 bh[C::PB], bl[C::PB];
+        unsigned ok;
     };
-    auto commit = [&](int buf) {
+    auto issue = [&](int kt, Regs& g) {
+        g.ok = 0u;
+#pragma unroll
+        for (int p = 0; p < C::PA; ++p) { g.a[p] = la(p, kt); g.ok |= (oka(p, kt) ? 1u : 0u) << p; }
+#pragma unroll
+        for (int p = 0; p < C::PB; ++p) { g.bh[p] = lb(p, kt, 0); g.bl[p] = lb(p, kt, 1); g.ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+    };
+    auto commit = [&](int buf, const Regs& g) {
 #pragma unroll
         for (int p = 0; p < C::PA; ++p) {
             const int row = arow + 32 * p;
-            float4 v = ra[p];
-            if (!((ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = g.a[p];
+            if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             half4 hi, lo;
             split4(v, a_scale, hi, lo);
             const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;
@@ -107,53 +112,94 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
 #pragma unroll
         for (int p = 0; p < C::PB; ++p) {
             const int row = brow + 64 * p;
-            uint4 vh = rbh[p], vl = rbl[p];
-            if (!((ok >> (8 + p)) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+            uint4 vh = g.bh[p], vl = g.bl[p];
+            if (!((g.ok >> (8 + p)) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
             const int off = row * BK + swz(bsl, row) * 8;
             *reinterpret_cast<uint4*>(&s.bh[buf][off]) = vh;
             *reinterpret_cast<uint4*>(&s.bl[buf][off]) = vl;
         }
     };
-    adv(0);
-    issue(0);
-    commit(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) { adv(kt + 1); issue(kt + 1); }
+    // Fragments of k-step 1 are requested before the MFMAs of k-step 0 (pinned with sched_barrier: hipcc otherwise sinks
+    // every ds_read next to its first use and each MFMA group starts with an exposed LDS round trip).
+    struct Frag {
+        half8 ah[MI], al[MI], bh[2], bl[2];
+    };
+    auto fload = [&](int cur, int ks, Frag& f) {
         const int arow0 = (wm * 32 * MI + r) * BK, brow0 = (wn * 64 + r) * BK;
+        const int slot = swz(2 * ks + h, r) * 8;      // tile rows differ from r by multiples of 32: same swizzle
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = swz(2 * ks + h, r) * 8;      // tile rows differ from r by multiples of 32: same swizzle
-            half8 ah[MI], al[MI], bh[2], bl[2];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                ah[mi] = *reinterpret_cast<const half8*>(&s.ah[cur][arow0 + mi * 32 * BK + slot]);
-                al[mi] = *reinterpret_cast<const half8*>(&s.al[cur][arow0 + mi * 32 * BK + slot]);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                bh[ni] = *reinterpret_cast<const half8*>(&s.bh[cur][brow0 + ni * 32 * BK + slot]);
-                bl[ni] = *reinterpret_cast<const half8*>(&s.bl[cur][brow0 + ni * 32 * BK + slot]);
-            }
-            // small terms first, the dominant hi.hi last: each accumulator sees lo.hi, hi.lo, hi.hi
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi) {
+            f.ah[mi] = *reinterpret_cast<const half8*>(&s.ah[cur][arow0 + mi * 32 * BK + slot]);
+            f.al[mi] = *reinterpret_cast<const half8*>(&s.al[cur][arow0 + mi * 32 * BK + slot]);
         }
-        if (more) commit(cur ^ 1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            f.bh[ni] = *reinterpret_cast<const half8*>(&s.bh[cur][brow0 + ni * 32 * BK + slot]);
+            f.bl[ni] = *reinterpret_cast<const half8*>(&s.bl[cur][brow0 + ni * 32 * BK + slot]);
+        }
+    };
+    auto fmma = [&](const Frag& f) {
+        // small terms first, the dominant hi.hi last: each accumulator sees lo.hi, hi.lo, hi.hi
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+    };
+    auto compute = [&](int cur) {
+        Frag f0, f1;
+        fload(cur, 0, f0);
+        fload(cur, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(f1);
+    };
+
+    if constexpr (C::PA <= 4) {
+        Regs g0, g1;
+        adv(0);
+        issue(0, g0);
+        if (nk > 1) { adv(1); issue(1, g1); }
+        commit(0, g0);
         __syncthreads();
+        // one step: chunk kt (in LDS buffer kt & 1) is multiplied; `fresh` = the set chunk kt came from (free again: receives
+        // chunk kt + 2), `next` = the set holding chunk kt + 1 (goes to LDS after the MFMAs)
+        auto step = [&](int kt, Regs& fresh, Regs& next) {
+            if (kt + 2 < nk) { adv(kt + 2); issue(kt + 2, fresh); }
+            __builtin_amdgcn_sched_barrier(0);   // the loads go out first; nothing of commit() (its waits!) moves above the MFMAs
+            compute(kt & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) commit((kt + 1) & 1, next);
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, g0, g1);
+            if (kt + 1 < nk) step(kt + 1, g1, g0);
+        }
+    } else {
+        // 256-row tiles (64-channel outputs): one register set — a second one does not fit beside 8 staging loads per thread
+        Regs g;
+        adv(0);
+        issue(0, g);
+        commit(0, g);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) { adv(kt + 1); issue(kt + 1, g); }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) commit((kt + 1) & 1, g);
+            __syncthreads();
+        }
     }
 }
 

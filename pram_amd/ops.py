@@ -319,16 +319,31 @@ def attention_h16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int,
     return (out, lse) if want_lse else out
 
 
-def attention_x3(q, k, v, batch: int, heads: int, m_max: int, n_max: int, scale: float,
+def value_planes_t(v, seqs: int, heads: int, t_max: int, lens: Optional[torch.Tensor] = None):
+    """(hi, lo) row-major value planes [seqs * t_max, >= heads * 64] (column slices of linear(split_out=...)'s planes) ->
+    the transposed, key-permuted planes [seqs, heads, 64, tv] attention_x3 stages with 16-byte copies; zeros beyond lens."""
+    L = _lib.load()
+    tv = (t_max + 63) // 64 * 64
+    out = torch.empty(2, seqs, heads, 64, tv, device=v[0].device, dtype=torch.float16)
+    assert v[0].stride(0) == v[1].stride(0) and v[0].stride(1) == 1 and v[0].dtype == torch.float16
+    _lib.check(L.pram_attention_x3_vt(_p(v[0]), _p(v[1]), v[0].stride(0), _p(out[0]), _p(out[1]), _p(lens), seqs, heads, t_max, _st()),
+               "pram_attention_x3_vt")
+    return out[0], out[1]
+
+
+def attention_x3(q, k, vt, batch: int, heads: int, m_max: int, n_max: int, scale: float,
                  q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None, want_lse: bool = False,
                  out: Optional[torch.Tensor] = None, kv_shift: int = 0):
-    """Split-fp16 flash attention.  q / k / v: (hi, lo) pairs of fp16 2-D views (column slices of the planes written by
-    linear(split_out=...)): fp32-class results, three fp16 MFMAs per product.  kv_shift: see attention_cross."""
+    """Split-fp16 flash attention.  q / k: (hi, lo) pairs of fp16 2-D views (column slices of the planes written by
+    linear(split_out=...)); vt: the (hi, lo) planes of value_planes_t for the key side.  fp32-class results, three fp16
+    MFMAs per product.  kv_shift: see attention_cross."""
     L = _lib.load()
-    for pair in (q, k, v):
+    for pair in (q, k):
         for t in pair:
             assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
         assert pair[0].stride(0) == pair[1].stride(0)
+    tv = (n_max + 63) // 64 * 64
+    assert vt[0].is_contiguous() and vt[1].is_contiguous() and vt[0].dtype == torch.float16 and vt[0].numel() == batch * heads * 64 * tv
     if out is None:
         out = torch.empty(batch * m_max, heads * 64, device=q[0].device, dtype=torch.float32)
     lse = torch.empty(batch, heads, m_max, device=q[0].device, dtype=torch.float32) if want_lse else None
@@ -336,8 +351,8 @@ def attention_x3(q, k, v, batch: int, heads: int, m_max: int, n_max: int, scale:
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.pram_attention_x3_f32(_p(q[0]), _p(q[1]), q[0].stride(0), _p(k[0]), _p(k[1]), k[0].stride(0), _p(v[0]), _p(v[1]),
-                                       v[0].stride(0), _p(out), out.stride(0), _p(lse), _p(q_lens), _p(k_lens), batch, heads,
+    _lib.check(L.pram_attention_x3_f32(_p(q[0]), _p(q[1]), q[0].stride(0), _p(k[0]), _p(k[1]), k[0].stride(0), _p(vt[0]), _p(vt[1]),
+                                       _p(out), out.stride(0), _p(lse), _p(q_lens), _p(k_lens), batch, heads,
                                        m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_x3_f32")
     if probe is not None:
         e1.record()

@@ -11,6 +11,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
            "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   name=$(echo $set | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --pmc $set -d "$OUT/$name" -o pmc --output-format csv -- \
-      python "$ROOT/bench.py" --steps 1 --warmup 1 --inflight 1 --cpu-queries 0 "$@" > "$OUT/$name.log" 2>&1
+      python "$ROOT/bench.py" --steps 1 --warmup 1 --inflight 1 --cpu-queries 0 --no-parity "$@" > "$OUT/$name.log" 2>&1
   echo "$name rc=$? $(ls $OUT/$name 2>/dev/null | tr '\n' ' ')"
 done

@@ -14,6 +14,9 @@ for f in glob.glob(os.path.join(src, "*", "*counter_collection.csv")):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"]).strip()
+        mm = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)(ILi(\d)ELi(\d)E)?", k)      # names the demangler gives up on (_Float16 pointers)
+        if mm:
+            k = mm.group(1) + (f"<{mm.group(3)}, {mm.group(4)}>" if mm.group(2) else "")
         vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r["Dispatch_Id"] not in seen and "FETCH_SIZE" in f:
             seen.add(r["Dispatch_Id"])
@@ -39,9 +42,14 @@ with open(os.path.join(root, "profiles", f"{tag}_pmc_summary.md"), "w") as o:
     for r in rows[:32]:
         o.write(f"| {r['kernel'][:60]} | {r['launches']} | {r['avg_us']:.1f} | {r['mfma']:.1f} | {r['fetch_kb']:.0f} | "
                 f"{2 * r['fetch_kb'] / 1024:.1f} | {r['write_kb']:.0f} | {(2 * r['fetch_kb'] + r['write_kb']) * 1024 / (r['avg_us'] * 1e3):.0f} | {r['lds']:.2f} | {r['wait']:.2f} |\n")
-att = next((r for r in rows if r["kernel"].startswith("attention_kernel")), None)
+# bench.py reads roofline.traffic from profiles/pmc_attention.json, keyed by the precision of the run (argv[3], default x3)
+prec = sys.argv[3] if len(sys.argv) > 3 else "x3"
+name = {"f32": "attention_kernel", "x3": "attention_x3_kernel", "f16": "attention_h16_kernel"}[prec]
+att = next((r for r in rows if r["kernel"].startswith(name)), None)
 if att:
-    js = {"attention_kernel": {"hbm_bytes_per_launch": (2 * att["fetch_kb"] + att["write_kb"]) * 1024, "fetch_size_kb": att["fetch_kb"],
-                               "write_size_kb": att["write_kb"], "mfma_util_pct": att["mfma"], "launches": att["launches"]}}
-    json.dump(js, open(os.path.join(root, "profiles", f"{tag}_pmc_attention.json"), "w"), indent=1)
-    print(json.dumps(js))
+    path = os.path.join(root, "profiles", "pmc_attention.json")
+    js = json.load(open(path)) if os.path.exists(path) else {}
+    js[prec] = {"kernel": name, "source": f"profiles/{tag}_pmc_summary.md", "hbm_bytes_per_launch": (2 * att["fetch_kb"] + att["write_kb"]) * 1024,
+                "fetch_size_kb": att["fetch_kb"], "write_size_kb": att["write_kb"], "mfma_util_pct": att["mfma"], "launches": att["launches"]}
+    json.dump(js, open(path, "w"), indent=1)
+    print(json.dumps(js[prec]))

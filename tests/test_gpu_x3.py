@@ -127,7 +127,8 @@ def test_attention_x3_vs_fp64(dev, B, M, N, ragged):
     ql = None if qlens is None else torch.tensor(qlens, dtype=torch.int32, device=dev)
     kl = None if klens is None else torch.tensor(klens, dtype=torch.int32, device=dev)
     o32 = ops.attention(qd, kd, vd, B, Hh, M, N, scale, ql, kl, precision="f32").view(B, M, -1)
-    ox3, lse = ops.attention_x3(_planes(ops, qd), _planes(ops, kd), _planes(ops, vd), B, Hh, M, N, scale, ql, kl, want_lse=True)
+    ox3, lse = ops.attention_x3(_planes(ops, qd), _planes(ops, kd), ops.value_planes_t(_planes(ops, vd), B, Hh, N, kl), B, Hh, M, N, scale,
+                                ql, kl, want_lse=True)
     ox3 = ox3.view(B, M, -1)
     _, lse32 = ops.attention(qd, kd, vd, B, Hh, M, N, scale, ql, kl, want_lse=True, precision="f32")
     e32 = ex3 = el = 0.0
@@ -148,10 +149,12 @@ def test_attention_x3_cross_equals_two_directions(dev):
     v = rnd(6, "cx/v", (2 * B * T, 256)).to(dev)
     lens = torch.tensor([384, 300, 200, 384], dtype=torch.int32, device=dev)
     pq, pv = _planes(ops, qk), _planes(ops, v)
-    both = ops.attention_x3(pq, pq, pv, 2 * B, 4, T, T, 0.125, lens, lens, kv_shift=B).view(2 * B, T, 256)
+    both = ops.attention_x3(pq, pq, ops.value_planes_t(pv, 2 * B, 4, T, lens), 2 * B, 4, T, T, 0.125, lens, lens, kv_shift=B).view(2 * B, T, 256)
     half = lambda pl, lo, hi: (pl[0][lo * T:hi * T], pl[1][lo * T:hi * T])
-    d01 = ops.attention_x3(half(pq, 0, B), half(pq, B, 2 * B), half(pv, B, 2 * B), B, 4, T, T, 0.125, lens[:B], lens[B:]).view(B, T, 256)
-    d10 = ops.attention_x3(half(pq, B, 2 * B), half(pq, 0, B), half(pv, 0, B), B, 4, T, T, 0.125, lens[B:], lens[:B]).view(B, T, 256)
+    vt1 = ops.value_planes_t(half(pv, B, 2 * B), B, 4, T, lens[B:].contiguous())
+    vt0 = ops.value_planes_t(half(pv, 0, B), B, 4, T, lens[:B].contiguous())
+    d01 = ops.attention_x3(half(pq, 0, B), half(pq, B, 2 * B), vt1, B, 4, T, T, 0.125, lens[:B].contiguous(), lens[B:].contiguous()).view(B, T, 256)
+    d10 = ops.attention_x3(half(pq, B, 2 * B), half(pq, 0, B), vt0, B, 4, T, T, 0.125, lens[B:].contiguous(), lens[:B].contiguous()).view(B, T, 256)
     for b in range(B):
         assert torch.equal(both[b, :int(lens[b])], d01[b, :int(lens[b])])
         assert torch.equal(both[B + b, :int(lens[B + b])], d10[b, :int(lens[B + b])])
@@ -167,10 +170,11 @@ def test_attention_x3_spike_and_empty(dev):
     k[700] = q[5] * 6.0          # a spike late in the key walk
     sp = lambda t, L: t.view(B, L, 4, 64).permute(0, 2, 1, 3)
     ref = _attn_ref(sp(q, M), sp(k, N), sp(v, N), 0.125).permute(0, 2, 1, 3).reshape(M, 256)
-    out = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), _planes(ops, v.to(dev)), B, 4, M, N, 0.125)
+    vt = ops.value_planes_t(_planes(ops, v.to(dev)), B, 4, N)
+    out = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), vt, B, 4, M, N, 0.125)
     assert err(out, ref) < 3e-6
     kl = torch.zeros(1, dtype=torch.int32, device=dev)
-    out0 = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), _planes(ops, v.to(dev)), B, 4, M, N, 0.125, None, kl)
+    out0 = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), vt, B, 4, M, N, 0.125, None, kl)
     assert float(out0.abs().max()) == 0.0
 
 
