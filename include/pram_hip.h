@@ -311,6 +311,14 @@ int pram_seg_epilogue_f32(const float* logits, const int* lens, int batch, int n
 int pram_row_sort_desc_f32(const float* x, int ld, int rows, int cols, float* vals, long long* idx,
                            void* stream);
 
+/* Landmark vote of MultiMap3D.process_segmentations (localization/multimap3d.py:348-379) on the sorted class lists of
+ * pram_row_sort_desc_f32 (sorted_ids / sorted_vals [n][c], c <= 1024): rank by rank, the landmarks that tokens put at sorted
+ * position k — background 0 and landmarks seen at an earlier rank skipped — ordered by token count (descending, ties by
+ * ascending id), until `topk` are collected.  Outputs (device): win_sid / win_rank / win_count [topk], *n_win, the winners'
+ * tokens in ascending order tokens [topk][n] (first win_count[w] of row w valid) and the mean of their rank-k scores. */
+int pram_seg_vote(const long long* sorted_ids, const float* sorted_vals, int n, int c, int topk, int* win_sid, int* win_rank,
+                  int* win_count, int* n_win, int* tokens, float* mean_score, void* stream);
+
 /* Row top-2 of a batched matrix (largest = 1: sim.topk(2), nearest_neighbor.py:5-17; largest = 0:
  * topk(largest=False), singlemap3d.py:428).  v0/v1 best and second best values, i0 index of the best
  * (lowest index on ties).  x [batch][m_max][ld]. */
@@ -324,6 +332,20 @@ int pram_row_top2_f32(const float* x, int ld, long long stride, const int* row_l
  * kpts [m][2], proj_uv [2][n] (u row then v row). */
 int pram_proj_dist_top2_f32(const float* sim, int ld, const float* kpts, const float* proj_uv, int m, int n,
                             float range, float* d0, float* d1, long long* i0, void* stream);
+
+/* The same with the projected points in float64 (what the reference actually holds: it projects in float64, so the pixel
+ * error and its `>= 2 * threshold` test are float64): proj_uv = [2][ldu] doubles, first n columns valid. */
+int pram_proj_dist_top2_f64uv(const float* sim, int ld, const float* kpts, const double* proj_uv, int ldu, int m, int n,
+                              double range, float* d0, float* d1, long long* i0, void* stream);
+
+/* Projection of the map points into the query camera + frustum test + ordered compaction
+ * (SingleMap3D.refine_pose_by_projection, localization/singlemap3d.py:405-415), float64 like the reference:
+ *   p = K (Tcw [X 1])[:3];  u = p0 / p2,  v = p1 / p2;  keep = 0 < p2 < 100, 0 <= u < im_w, 0 <= v < im_h.
+ * xyz [n][3]; K [3][3], Tcw [4][4] row-major (device); uvd [3][n] = u, v, depth of EVERY point; mask [n] int32;
+ * keep_idx [n] = original indices of the survivors in their original order, uv_keep [2][n] their (u, v) (first *count
+ * columns valid); count = number of survivors (device int). */
+int pram_project_points_f64(const double* xyz, const double* K, const double* Tcw, int n, double im_w, double im_h,
+                            double* uvd, int* mask, int* keep_idx, double* uv_keep, int* count, void* stream);
 
 #ifdef __cplusplus
 }

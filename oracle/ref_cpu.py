@@ -573,6 +573,36 @@ def match_by_projection(q_kpts, q_descs, proj_uvs, ref_descs, threshold: float):
     return (ratios <= 0.995) & (dists[:, 0] < 100), ids[:, 0], dists
 
 
+def project_map_points(xyzs, K, Tcw, imw: int, imh: int):
+    """SingleMap3D.refine_pose_by_projection, projection + frustum test — localization/singlemap3d.py:405-415, float64 like
+    the reference.  -> (proj_uvs [3, n_keep] of the survivors, mask [N])."""
+    X = torch.as_tensor(np.asarray(xyzs), dtype=torch.float64)
+    homo = torch.cat([X, torch.ones(X.shape[0], 1, dtype=X.dtype)], dim=1)
+    proj = torch.as_tensor(np.asarray(K), dtype=torch.float64) @ (torch.as_tensor(np.asarray(Tcw), dtype=torch.float64) @ homo.t())[:3, :]
+    proj[0] /= proj[2]
+    proj[1] /= proj[2]
+    mask = (proj[2] > 0) * (proj[2] < 100) * (proj[0] >= 0) * (proj[0] < imw) * (proj[1] >= 0) * (proj[1] < imh)
+    return proj[:, mask], mask
+
+
+def refine_matches_by_projection(q_kpts, q_descs, xyzs, descs, K, Tcw, imw: int, imh: int, threshold: float) -> dict:
+    """The device part of SingleMap3D.refine_pose_by_projection — localization/singlemap3d.py:405-444: what it hands to the pose
+    solver (matched keypoint ids, the map points they matched)."""
+    proj_uvs, mask = project_map_points(xyzs, K, Tcw, imw, imh)
+    kp = torch.as_tensor(np.asarray(q_kpts))[:, :2]
+    proj_error = torch.sqrt(torch.sum((kp[..., None] - proj_uvs[:2][None]) ** 2, dim=1))
+    out_of_range = proj_error >= 2 * threshold
+    qd = torch.as_tensor(np.asarray(q_descs)).float()
+    rd = torch.as_tensor(np.asarray(descs)).float()[mask]
+    desc_dist = torch.sqrt(2 - 2 * qd @ rd.t() + 1e-6)
+    desc_dist[out_of_range] = desc_dist[out_of_range] + 100
+    dists, ids = _top2(desc_dist, False)
+    ratio_mask = ((dists[:, 0] / dists[:, 1]) <= 0.995) & (dists[:, 0] < 100)
+    keep = torch.nonzero(mask).flatten()
+    return {"point_mask": mask, "ratio_mask": ratio_mask, "matched_keypoint_ids": torch.nonzero(ratio_mask).flatten(),
+            "matched_point_ids": keep[ids[:, 0][ratio_mask]], "dists": dists}
+
+
 def mask_labelling(keypoints, scores, descriptors, mask, topK=-1) -> dict:
     """extract_sfd2_return's mask branch — nets/sfd2.py:508-571, kept as the reference's per-keypoint loop.  Ties in the
     two score sorts are broken by (score desc, index asc) instead of numpy's unspecified quicksort order."""
@@ -650,9 +680,10 @@ def extract_sfd2_return(sd: SD, img: torch.Tensor, conf_th=0.001, topK=-1, scale
 
 
 # ------------------------------------------------------------------ edge formats
-# Parity status of this block: the reference modules that hold these lines import h5py, which is not installed, so
-# they cannot be executed here — the conversions are restated from the cited lines (UNPINNED by execution; the
-# arithmetic is three casts and one affine map).
+# Parity status of this block: PINNED.  oracle/gen_golden.py::gen_formats executes the reference's own
+# FeaturePairsDataset.__getitem__, writer_fn, find_unique_new_pairs (localization/match_features_batch.py), the export loop of
+# localization/extract_features.py::main and colmap_utils/parsers.py with h5py replaced by an in-memory group store (h5py is not
+# installed; the container itself is the one thing that cannot run here) and asserts equality with the functions below.
 def names_to_pair(name0: str, name1: str, separator: str = "/") -> str:
     """colmap_utils/parsers.py:79-80"""
     return separator.join((name0.replace("/", "-"), name1.replace("/", "-")))
@@ -691,3 +722,29 @@ def pair_item(grp0: dict, grp1: dict) -> dict:
                 data[k + sfx] = data[k + sfx].t()
         data["image" + sfx] = torch.empty((1,) + tuple(grp["image_size"])[::-1])
     return data
+
+
+def parse_retrieval(path) -> dict:
+    """colmap_utils/parsers.py:57-63"""
+    from collections import defaultdict
+    out = defaultdict(list)
+    with open(path, "r") as f:
+        for line in f.read().rstrip("\n").split("\n"):
+            q, r = line.split(" ")
+            out[q].append(r)
+    return dict(out)
+
+
+def find_unique_new_pairs(pairs_all, existing=None):
+    """localization/match_features_batch.py:165-186: (j, i) dropped when (i, j) came first; pairs already stored under either
+    order / either naming dropped.  ``existing`` = container of stored group names (anything supporting ``in``).  The reference
+    returns list(set(...)) — arbitrary order — so this returns a set."""
+    pairs = set()
+    for i, j in pairs_all:
+        if (j, i) not in pairs:
+            pairs.add((i, j))
+    if existing is None:
+        return pairs
+    old_name = lambda a, b: names_to_pair(a, b, separator="_")
+    return {(i, j) for i, j in pairs
+            if not (names_to_pair(i, j) in existing or names_to_pair(j, i) in existing or old_name(i, j) in existing or old_name(j, i) in existing)}

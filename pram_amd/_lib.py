@@ -59,6 +59,9 @@ _SIGS = {
     "pram_row_sort_desc_f32": (I, [P, I, I, I, P, P, P]),
     "pram_row_top2_f32": (I, [P, I, LL, P, P, I, I, I, I, P, P, P, P]),
     "pram_proj_dist_top2_f32": (I, [P, I, P, P, I, I, F, P, P, P, P]),
+    "pram_proj_dist_top2_f64uv": (I, [P, I, P, P, I, I, I, C.c_double, P, P, P, P]),
+    "pram_project_points_f64": (I, [P, P, P, I, C.c_double, C.c_double, P, P, P, P, P, P]),
+    "pram_seg_vote": (I, [P, P, I, I, I, P, P, P, P, P, P, P]),
     "pram_score_lookup_f32": (I, [P, LL, I, I, P, P, I, I, P, P]),
 }
 

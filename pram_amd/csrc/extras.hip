@@ -186,7 +186,200 @@ __global__ __launch_bounds__(256) void proj_top2_kernel(const float* __restrict_
     if (lane == 0) { d0[row] = a0; d1[row] = a1; i0[row] = (n > 0) ? j0 : -1; }
 }
 
+// ---- landmark vote of MultiMap3D.process_segmentations (multimap3d.py:348-379) on the device ---------------------------
+// idx / vals [n][c]: every token's classes sorted by score (row_sort_kernel).  Rank k = 0, 1, ...: the landmarks that tokens
+// put at sorted position k, skipping background (0) and landmarks already seen at an earlier rank, ordered by the number of
+// such tokens (descending; equal counts in ascending landmark id — Python's stable sort over np.unique's ascending ids),
+// until `topk` landmarks are collected.  One workgroup: class histograms in LDS, winners by repeated block arg-max.
+constexpr int VOTE_MAX_C = 1024;
+
+__global__ __launch_bounds__(1024) void seg_vote_kernel(const long long* __restrict__ idx, int n, int c, int topk,
+                                                        int* __restrict__ win_sid, int* __restrict__ win_rank,
+                                                        int* __restrict__ win_cnt, int* __restrict__ n_win) {
+    __shared__ int cnt[VOTE_MAX_C];
+    __shared__ unsigned char used[VOTE_MAX_C];
+    __shared__ long long wbest[16];
+    __shared__ int nsel, left;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < VOTE_MAX_C) used[tid] = 0;
+    if (tid == 0) nsel = 0;
+    __syncthreads();
+    for (int k = 0; k < c; ++k) {
+        if (nsel >= topk) break;
+        if (tid < VOTE_MAX_C) cnt[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < n; t += 1024) atomicAdd(&cnt[(int)idx[(size_t)t * c + k]], 1);
+        __syncthreads();
+        // candidates of this rank: seen here, not background, not used before; all of them count as used from now on
+        const bool cand0 = tid < c && tid != 0 && cnt[tid] > 0 && !used[tid];
+        if (tid < c && cnt[tid] > 0) used[tid] = 1;
+        bool cand = cand0;
+        for (;;) {
+            // block arg-max of (count, lowest id): key = count * 2048 + (2047 - id)
+            long long key = cand ? ((long long)cnt[tid] * 2048 + (2047 - tid)) : -1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
+            if (lane == 0) wbest[wave] = key;
+            __syncthreads();
+            long long best = -1;
+            for (int w = 0; w < 16; ++w) best = max(best, wbest[w]);
+            if (tid == 0) left = (best >= 0);
+            if (best >= 0) {
+                const int sid = 2047 - (int)(best % 2048);
+                if (tid == sid) {
+                    cand = false;
+                    const int o = nsel;
+                    win_sid[o] = sid; win_rank[o] = k; win_cnt[o] = cnt[sid];
+                    nsel = o + 1;
+                }
+            }
+            __syncthreads();
+            if (!left || nsel >= topk) break;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_win = nsel;
+}
+
+// per winner (one wave each): its tokens in ascending order and the mean of their rank-k scores (fixed summation order)
+__global__ __launch_bounds__(64) void seg_vote_gather_kernel(const long long* __restrict__ idx, const float* __restrict__ vals,
+                                                             int n, int c, const int* __restrict__ win_sid,
+                                                             const int* __restrict__ win_rank, const int* __restrict__ n_win,
+                                                             int* __restrict__ tokens, float* __restrict__ mean) {
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (w >= *n_win) return;
+    const int sid = win_sid[w], k = win_rank[w];
+    int base = 0;
+    double part = 0.0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        const bool f = t < n && (int)idx[(size_t)t * c + k] == sid;
+        const unsigned long long bal = __ballot(f);
+        if (f) {
+            tokens[(size_t)w * n + base + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+            part += (double)vals[(size_t)t * c + k];
+        }
+        base += __popcll(bal);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) mean[w] = (float)(part / (double)base);
+}
+
+// Same with the projected points in double precision: the reference projects in float64 (numpy poses / intrinsics) and
+// float32 keypoint - float64 projection promotes the pixel error and its `>= 2 * threshold` test to float64.
+__global__ __launch_bounds__(256) void proj_top2_f64_kernel(const float* __restrict__ sim, int ld, const float* __restrict__ kpts,
+                                                            const double* __restrict__ uv, int ldu, int m, int n, double range,
+                                                            float* __restrict__ d0, float* __restrict__ d1,
+                                                            long long* __restrict__ i0) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const double kx = (double)kpts[row * 2], ky = (double)kpts[row * 2 + 1];
+    const float* p = sim + (size_t)row * ld;
+    float a0 = INFINITY, a1 = INFINITY;
+    int j0 = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const double ex = kx - uv[j], ey = ky - uv[ldu + j];
+        const double pe = sqrt(ex * ex + ey * ey);
+        float v = sqrtf((2.f - 2.f * p[j]) + 1e-6f);
+        if (pe >= range) v = v + 100.f;
+        if (v < a0) { a1 = a0; a0 = v; j0 = j; }
+        else if (v < a1) a1 = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float b0 = __shfl_xor(a0, o, 64), b1 = __shfl_xor(a1, o, 64);
+        const int k0 = __shfl_xor(j0, o, 64);
+        if (b0 < a0 || (b0 == a0 && k0 < j0)) { a1 = fminf(a0, b1); a0 = b0; j0 = k0; }
+        else a1 = fminf(a1, b0);
+    }
+    if (lane == 0) { d0[row] = a0; d1[row] = a1; i0[row] = (n > 0) ? j0 : -1; }
+}
+
+// ---- projection of the map points (SingleMap3D.refine_pose_by_projection, singlemap3d.py:405-415), float64 like the reference:
+// p = K (Tcw [X 1])[:3];  u = p0 / p2, v = p1 / p2;  keep = 0 < p2 < 100 and 0 <= u < w and 0 <= v < h
+__global__ void proj_points_kernel(const double* __restrict__ xyz, const double* __restrict__ K, const double* __restrict__ T,
+                                   int n, double imw, double imh, double* __restrict__ uvd, int* __restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    double c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) c[r] = ((T[r * 4] * x + T[r * 4 + 1] * y) + T[r * 4 + 2] * z) + T[r * 4 + 3];
+    double p[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p[r] = (K[r * 3] * c[0] + K[r * 3 + 1] * c[1]) + K[r * 3 + 2] * c[2];
+    const double u = p[0] / p[2], v = p[1] / p[2];
+    uvd[i] = u;
+    uvd[n + i] = v;
+    uvd[2 * n + i] = p[2];
+    mask[i] = (p[2] > 0.0) && (p[2] < 100.0) && (u >= 0.0) && (u < imw) && (v >= 0.0) && (v < imh);
+}
+
+// ordered stream compaction of the survivors (the reference's boolean indexing keeps the original order): one workgroup walks the
+// array in chunks of 1024 with a block scan; writes the surviving original indices, their (u, v) and the count
+__global__ __launch_bounds__(1024) void proj_compact_kernel(const int* __restrict__ mask, const double* __restrict__ uvd, int n,
+                                                            int* __restrict__ keep_idx, double* __restrict__ uv_keep,
+                                                            int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const int f = (i < n) ? (mask[i] != 0) : 0;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+        const int b = base;
+        if (f) {
+            const int o = b + woff + before;
+            keep_idx[o] = i;
+            uv_keep[o] = uvd[i];
+            uv_keep[n + o] = uvd[n + i];
+        }
+        __syncthreads();
+        if (tid == 0) base = b + tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+
 }  // namespace
+
+extern "C" int pram_seg_vote(const long long* sorted_ids, const float* sorted_vals, int n, int c, int topk, int* win_sid,
+                             int* win_rank, int* win_count, int* n_win, int* tokens, float* mean_score, void* stream) {
+    PRAM_REQUIRE(sorted_ids && sorted_vals && win_sid && win_rank && win_count && n_win && tokens && mean_score, "pram_seg_vote: null pointer");
+    PRAM_REQUIRE(c > 0 && c <= VOTE_MAX_C && topk > 0 && n >= 0, "pram_seg_vote: needs 0 < classes <= %d, topk > 0", VOTE_MAX_C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seg_vote_kernel, dim3(1), dim3(1024), 0, st, sorted_ids, n, c, topk, win_sid, win_rank, win_count, n_win);
+    hipLaunchKernelGGL(seg_vote_gather_kernel, dim3(topk), dim3(64), 0, st, sorted_ids, sorted_vals, n, c, win_sid, win_rank, n_win,
+                       tokens, mean_score);
+    return pram_launch_status("pram_seg_vote");
+}
+
+extern "C" int pram_project_points_f64(const double* xyz, const double* K, const double* Tcw, int n, double im_w, double im_h,
+                                       double* uvd, int* mask, int* keep_idx, double* uv_keep, int* count, void* stream) {
+    PRAM_REQUIRE(xyz && K && Tcw && uvd && mask && keep_idx && uv_keep && count, "pram_project_points_f64: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n > 0) hipLaunchKernelGGL(proj_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, xyz, K, Tcw, n, im_w, im_h, uvd, mask);
+    hipLaunchKernelGGL(proj_compact_kernel, dim3(1), dim3(1024), 0, st, mask, uvd, n, keep_idx, uv_keep, count);
+    return pram_launch_status("pram_project_points_f64");
+}
+
+extern "C" int pram_proj_dist_top2_f64uv(const float* sim, int ld, const float* kpts, const double* proj_uv, int ldu, int m, int n,
+                                         double range, float* d0, float* d1, long long* i0, void* stream) {
+    PRAM_REQUIRE(sim && kpts && proj_uv && d0 && d1 && i0, "pram_proj_dist_top2_f64uv: null pointer");
+    if (m == 0) return PRAM_OK;
+    hipLaunchKernelGGL(proj_top2_f64_kernel, dim3(cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, sim, ld, kpts, proj_uv, ldu, m, n,
+                       range, d0, d1, i0);
+    return pram_launch_status("pram_proj_dist_top2_f64uv");
+}
 
 extern "C" int pram_proj_dist_top2_f32(const float* sim, int ld, const float* kpts, const float* proj_uv, int m, int n,
                                        float range, float* d0, float* d1, long long* i0, void* stream) {

@@ -700,3 +700,55 @@ def proj_dist_top2(sim: torch.Tensor, kpts: torch.Tensor, proj_uv: torch.Tensor,
     _lib.check(L.pram_proj_dist_top2_f32(_p(sim), ld, _p(kpts), _p(proj_uv), M, N, float(rng), _p(d0), _p(d1), _p(i0), _st()),
                "pram_proj_dist_top2_f32")
     return d0, d1, i0
+
+
+def proj_dist_top2_f64uv(sim: torch.Tensor, kpts: torch.Tensor, proj_uv: torch.Tensor, rng: float, n_valid: int):
+    """proj_dist_top2 with float64 projections [2, ldu] (first n_valid columns valid): the pixel error and its `>= rng` test
+    are float64, as in the reference (float32 keypoints - float64 projections)."""
+    L = _lib.load()
+    assert sim.is_contiguous() and sim.dim() == 2 and proj_uv.dtype == torch.float64 and proj_uv.is_contiguous() and proj_uv.dim() == 2
+    M, ld = sim.shape
+    kpts = kpts.contiguous().float()
+    d0 = torch.zeros(M, device=sim.device, dtype=torch.float32)
+    d1 = torch.zeros(M, device=sim.device, dtype=torch.float32)
+    i0 = torch.full((M,), -1, device=sim.device, dtype=_INT64)
+    _lib.check(L.pram_proj_dist_top2_f64uv(_p(sim), ld, _p(kpts), _p(proj_uv), proj_uv.shape[1], M, int(n_valid), float(rng), _p(d0), _p(d1),
+                                           _p(i0), _st()), "pram_proj_dist_top2_f64uv")
+    return d0, d1, i0
+
+
+def project_points(xyz: torch.Tensor, K: torch.Tensor, Tcw: torch.Tensor, im_w: float, im_h: float):
+    """xyz [N,3], K [3,3], Tcw [4,4] float64 on the device -> (uvd [3,N] f64, mask int32 [N], keep_idx int32 [N], uv_keep f64 [2,N],
+    count int32 [1]) — projection, frustum test and ordered compaction of singlemap3d.py:405-415; nothing synchronises."""
+    L = _lib.load()
+    for t, nm in ((xyz, "xyz"), (K, "K"), (Tcw, "Tcw")):
+        _chk(t, nm, torch.float64)
+    xyz, K, Tcw = xyz.contiguous(), K.contiguous(), Tcw.contiguous()
+    n = xyz.shape[0]
+    dev = xyz.device
+    uvd = torch.empty(3, n, device=dev, dtype=torch.float64)
+    mask = torch.empty(n, device=dev, dtype=torch.int32)
+    keep = torch.empty(n, device=dev, dtype=torch.int32)
+    uvk = torch.empty(2, max(n, 1), device=dev, dtype=torch.float64)
+    count = torch.zeros(1, device=dev, dtype=torch.int32)
+    _lib.check(L.pram_project_points_f64(_p(xyz), _p(K), _p(Tcw), n, float(im_w), float(im_h), _p(uvd), _p(mask), _p(keep), _p(uvk),
+                                         _p(count), _st()), "pram_project_points_f64")
+    return uvd, mask, keep, uvk, count
+
+
+def seg_vote(sorted_vals: torch.Tensor, sorted_ids: torch.Tensor, topk: int):
+    """Landmark vote over the sorted class lists of row_sort_desc ([N, C] each) -> device tensors
+    (win_sid [topk], win_rank [topk], win_count [topk], n_win [1], tokens [topk, N], mean_score [topk])."""
+    L = _lib.load()
+    assert sorted_vals.is_contiguous() and sorted_ids.is_contiguous() and sorted_ids.dtype == _INT64
+    n, c = sorted_vals.shape
+    dev = sorted_vals.device
+    sid = torch.zeros(topk, device=dev, dtype=torch.int32)
+    rank = torch.zeros(topk, device=dev, dtype=torch.int32)
+    cnt = torch.zeros(topk, device=dev, dtype=torch.int32)
+    nwin = torch.zeros(1, device=dev, dtype=torch.int32)
+    tokens = torch.zeros(topk, max(n, 1), device=dev, dtype=torch.int32)
+    mean = torch.zeros(topk, device=dev, dtype=torch.float32)
+    _lib.check(L.pram_seg_vote(_p(sorted_ids), _p(sorted_vals), n, c, int(topk), _p(sid), _p(rank), _p(cnt), _p(nwin), _p(tokens), _p(mean),
+                               _st()), "pram_seg_vote")
+    return sid, rank, cnt, nwin, tokens, mean

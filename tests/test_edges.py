@@ -22,6 +22,23 @@ def _proj_inputs():
     return pair["keypoints0"], pair["descriptors0"], pair["descriptors1"]
 
 
+def _projrefine_inputs(g):
+    """inputs of the projrefine golden: geometry is stored, descriptors regenerate from their seeds (oracle/gen_golden.py::gen_projection)"""
+    seed, N, M, D = (int(x) for x in g["descs_key"])
+    descs = torch.nn.functional.normalize(W.normal(seed, "pj/d", (N, D), 1.0), dim=-1).numpy()
+    pick = g["pick_ids"]
+    qd = descs[pick] + W.normal(seed, "pj/dn", (len(pick), D), 0.35 / D ** 0.5).numpy()
+    qd = np.concatenate([qd, W.normal(seed, "pj/cd", (150, D), 1.0).numpy()])
+    qd = (qd / np.linalg.norm(qd, axis=1, keepdims=True)).astype(np.float32)
+    from scipy.spatial.transform import Rotation
+    q = g["qvec"]
+    Tcw = np.eye(4)
+    Tcw[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()      # colmap quaternions are (w, x, y, z)
+    Tcw[:3, 3] = g["tvec"]
+    return dict(q_kpts=g["keypoints"], q_descs=qd, xyzs=g["xyz"], descs=descs, K=g["K"], Tcw=Tcw, im_w=int(g["imw"]), im_h=int(g["imh"]),
+                threshold=float(g["threshold"]))
+
+
 def _offline_image():
     return W.uniform(77, "offline/img", (1, 3, 96, 128), 0.0, 1.0) * 0.5 + 0.5 * torch.nn.functional.interpolate(
         W.uniform(77, "offline/coarse", (1, 3, 7, 9), 0.0, 1.0), size=(96, 128), mode="bilinear", align_corners=True)
@@ -160,6 +177,53 @@ def test_hip_projection_matching(dev, golden):
     assert np.array_equal(m.cpu().numpy(), g["ratio_mask"])
     assert np.array_equal(i.cpu().numpy()[g["ratio_mask"]], g["ids"][g["ratio_mask"]])
     assert np.abs(d.cpu().numpy() - g["dists"]).max() < 1e-4
+
+
+def test_oracle_projection_refinement(golden):
+    """(f)2 complete: projection + frustum test + compaction + masked top-2, against what the imported
+    SingleMap3D.refine_pose_by_projection handed to its pose solver (golden)."""
+    g = golden("projrefine_n1500_m600")
+    a = _projrefine_inputs(g)
+    o = R.refine_matches_by_projection(a["q_kpts"], a["q_descs"], a["xyzs"], a["descs"], a["K"], a["Tcw"], a["im_w"], a["im_h"], a["threshold"])
+    assert np.array_equal(o["point_mask"].numpy(), g["point_mask"])
+    assert np.array_equal(o["matched_keypoint_ids"].numpy(), g["matched_keypoint_ids"])
+    assert np.array_equal(o["matched_point_ids"].numpy(), g["matched_point_ids"])
+
+
+@pytest.mark.gpu
+def test_hip_projection_refinement(dev, golden):
+    from pram_amd.localization import recognition_post as P
+    g = golden("projrefine_n1500_m600")
+    a = _projrefine_inputs(g)
+    r = P.refine_matches_by_projection(a["q_kpts"], a["q_descs"], a["xyzs"], a["descs"], a["K"], a["Tcw"], a["im_w"], a["im_h"], a["threshold"])
+    assert np.array_equal(r["point_mask"].cpu().numpy(), g["point_mask"])
+    assert np.array_equal(r["matched_keypoint_ids"].cpu().numpy(), g["matched_keypoint_ids"])
+    assert np.array_equal(r["matched_point_ids"].cpu().numpy(), g["matched_point_ids"])
+    assert np.abs(r["dists"].cpu().numpy() - g["dists"]).max() < 1e-4
+    uv, mask = P.project_map_points(a["xyzs"], a["K"], a["Tcw"], a["im_w"], a["im_h"])
+    ou, om = R.project_map_points(a["xyzs"], a["K"], a["Tcw"], a["im_w"], a["im_h"])
+    assert torch.equal(mask.cpu(), om) and float((uv.cpu() - ou).abs().max()) < 1e-9
+    # degenerate inputs: no map point in the frustum, no query keypoints
+    far = a["xyzs"] + np.array([0.0, 0.0, 500.0])
+    r0 = P.refine_matches_by_projection(a["q_kpts"], a["q_descs"], far, a["descs"], a["K"], a["Tcw"], a["im_w"], a["im_h"], a["threshold"])
+    assert int(r0["point_mask"].sum()) == 0 and r0["matched_keypoint_ids"].numel() == 0
+
+
+@pytest.mark.gpu
+def test_hip_landmark_vote_matches_the_host_loop(dev):
+    """process_segmentations on the device (class histograms per sorted position) == the reference's host loop (oracle) on
+    inputs that need several ranks, have count ties and a dominant background."""
+    from pram_amd.localization import recognition_post as P
+    for seed, n, c, topk in ((1, 300, 17, 10), (2, 64, 9, 30), (3, 1200, 113, 20), (4, 5, 6, 4)):
+        logits = W.normal(seed, "vote/l", (n, c), 2.0)
+        logits[:, 0] += 1.5
+        logits[:, 1 + seed % (c - 1)] += 2.0            # one dominant landmark -> the later ranks get used too
+        segs = torch.softmax(logits, -1)
+        want = R.process_segmentations(segs, topk=topk)
+        got = P.process_segmentations(segs.to(dev), topk=topk)
+        assert [int(p[0]) for p in got] == [int(p[0]) for p in want], seed
+        for a, b in zip(got, want):
+            assert np.array_equal(a[1], b[1]) and abs(float(a[2]) - float(b[2])) < 1e-6
 
 
 @pytest.mark.gpu

@@ -118,3 +118,33 @@ def test_match_pairs_batched_equals_reference_loop(tmp_path):
         m2, s2 = F.read_matches(out2, a, b)
         assert np.array_equal(m, m2) and np.array_equal(s.view(np.uint16), s2.view(np.uint16))
     assert F.names_to_pair(*pairs[0]) not in out2
+
+
+def test_formats_reproduce_the_reference_files(golden):
+    """tests/golden/formats_pinned.npz holds what the reference's OWN code wrote / read (extract_features.main's export loop,
+    FeaturePairsDataset.__getitem__, writer_fn) when oracle/gen_golden.py::gen_formats ran it against an in-memory h5py
+    stand-in; the product functions must reproduce those arrays bit for bit, dtypes included."""
+    import numpy as np
+    import torch
+    from pram_amd import weights as W
+    from pram_amd.localization import formats as F2
+    g = golden("formats_pinned")
+    store = F2.DictStore()
+    for i, (name, n, hw, orig) in enumerate((("db/3.jpg", 57, (480, 640), (1280, 960)), ("q/1.jpg", 40, (240, 320), (320, 240)))):
+        pred = {"keypoints": np.floor(W.uniform(40 + i, "ff/k", (n, 2), 4.0, 200.0).numpy()).astype(np.float64),
+                "scores": W.uniform(40 + i, "ff/s", (n,), 0.0, 1.0).numpy().astype(np.float64),
+                "descriptors": W.normal(40 + i, "ff/d", (n, 128), 1.0).numpy().astype(np.float64)}
+        enc = F2.encode_features(pred, hw, np.array(orig))
+        for k in ("descriptors", "keypoints", "scores", "image_size"):
+            want = g[f"feat_{i}_{k}"]
+            assert np.asarray(enc[k]).dtype == want.dtype and np.array_equal(enc[k], want), (name, k)
+        F2.write_features(store, name, enc)
+    item = F2.read_feature_pair(store, "q/1.jpg", store, "db/3.jpg")
+    for k, v in item.items():
+        if k in ("image0", "image1"):
+            assert tuple(v.shape) == tuple(g[f"item_{k}_shape"])
+        else:
+            assert v.dtype == torch.float32 and np.array_equal(v.numpy(), g[f"item_{k}"]), k
+    enc = F2.encode_matches(torch.from_numpy(g["write_m0"])[0], torch.from_numpy(g["write_s0"])[0])
+    assert enc["matches0"].dtype == np.int16 and np.array_equal(enc["matches0"], g["write_matches0"])
+    assert enc["matching_scores0"].dtype == np.float16 and np.array_equal(enc["matching_scores0"], g["write_matching_scores0"])
