@@ -85,6 +85,16 @@ int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int l
                        int ldo16, int m, int n, float alpha, int flags, const float* rot_cos,
                        const float* rot_sin, int rot_cols, void* stream);
 
+/* pram_linear_x3_f32 with the activations already split: [A0 | A1] given as fp16 planes (value * 16 = hi + lo, [m][lda]
+ * halves) written by the epilogues of pram_linear_x3[p]_f32 / pram_attention_x3_f32 / pram_layernorm_gelu_x3.  Both operands are
+ * then staged with plain 16-byte copies (the fp32-input form splits A again in every column tile and is instruction-issue
+ * bound).  k0, k1 multiples of 32; lda multiples of 8. */
+int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda0, int k0, const void* a1_hi, const void* a1_lo,
+                        int lda1, int k1, const void* w_hi, const void* w_lo, float w_scale, const float* bias,
+                        const float* residual, int ldr, float* out, int ldo, void* out_hi, void* out_lo, int ldo16,
+                        int m, int n, float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                        void* stream);
+
 /* Batched C_b = alpha * A_b · B_bᵀ (einsum 'bmd,bnd->bmn', nets/gml.py:282; K12).
  * A_b = a + b*stride_a, [m_max][lda]; B_b [n_max][ldb]; C_b [m_max][ldc]. */
 int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,

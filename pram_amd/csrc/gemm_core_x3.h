@@ -203,4 +203,128 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
     }
 }
 
+// ---- both operands pre-split in HBM ("planes"): A = two fp16 planes [rows][K] written by a producer's epilogue
+// (linear / attention / LayerNorm kernels on the x3 path), B = the host-split weights.  Staging is then a pure copy — 16-byte
+// loads and ds_write_b128, no conversion arithmetic: the split main loop above is INSTRUCTION-ISSUE bound (150 VALU per 24
+// MFMAs per chunk, most of it splitting A again in every column tile), this one is left with ~40 non-MFMA instructions.
+// PLoad(p, kt, plane) -> raw uint4 of rows tid/4 + 64p, halves kt*32 + (tid%4)*8 ..+7 of the plane; POk(p, kt) its predicate.
+template <int MI, int WN, class ALoad, class AOk, class BLoad, class BOk>
+__device__ __forceinline__ void mainloop_planes(Smem<MI, WN>& s, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                                f32x16 (&acc)[MI][2]) {
+    using C = Cfg<MI, WN>;
+    constexpr int QA = C::BM / 64, QB = C::BN / 64;      // 16-byte loads per thread and plane
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int srow = tid >> 2, ssl = tid & 3;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    struct Regs {
+        uint4 ah[QA], al[QA], bh[QB], bl[QB];
+        unsigned ok;
+    };
+    auto issue = [&](int kt, Regs& g) {
+        g.ok = 0u;
+#pragma unroll
+        for (int p = 0; p < QA; ++p) { g.ah[p] = la(p, kt, 0); g.al[p] = la(p, kt, 1); g.ok |= (oka(p, kt) ? 1u : 0u) << p; }
+#pragma unroll
+        for (int p = 0; p < QB; ++p) { g.bh[p] = lb(p, kt, 0); g.bl[p] = lb(p, kt, 1); g.ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+    };
+    auto commit = [&](int buf, const Regs& g) {
+#pragma unroll
+        for (int p = 0; p < QA; ++p) {
+            const int row = srow + 64 * p;
+            uint4 vh = g.ah[p], vl = g.al[p];
+            if (!((g.ok >> p) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+            const int off = row * BK + swz(ssl, row) * 8;
+            *reinterpret_cast<uint4*>(&s.ah[buf][off]) = vh;
+            *reinterpret_cast<uint4*>(&s.al[buf][off]) = vl;
+        }
+#pragma unroll
+        for (int p = 0; p < QB; ++p) {
+            const int row = srow + 64 * p;
+            uint4 vh = g.bh[p], vl = g.bl[p];
+            if (!((g.ok >> (8 + p)) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+            const int off = row * BK + swz(ssl, row) * 8;
+            *reinterpret_cast<uint4*>(&s.bh[buf][off]) = vh;
+            *reinterpret_cast<uint4*>(&s.bl[buf][off]) = vl;
+        }
+    };
+    struct Frag {
+        half8 ah[MI], al[MI], bh[2], bl[2];
+    };
+    auto fload = [&](int cur, int ks, Frag& f) {
+        const int arow0 = (wm * 32 * MI + r) * BK, brow0 = (wn * 64 + r) * BK;
+        const int slot = swz(2 * ks + h, r) * 8;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            f.ah[mi] = *reinterpret_cast<const half8*>(&s.ah[cur][arow0 + mi * 32 * BK + slot]);
+            f.al[mi] = *reinterpret_cast<const half8*>(&s.al[cur][arow0 + mi * 32 * BK + slot]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            f.bh[ni] = *reinterpret_cast<const half8*>(&s.bh[cur][brow0 + ni * 32 * BK + slot]);
+            f.bl[ni] = *reinterpret_cast<const half8*>(&s.bl[cur][brow0 + ni * 32 * BK + slot]);
+        }
+    };
+    auto fmma = [&](const Frag& f) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+    };
+    auto body = [&](int kt) {
+        Frag f0, f1;
+        fload(kt & 1, 0, f0);
+        fload(kt & 1, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (QA <= 2) {
+        Regs g0, g1;
+        issue(0, g0);
+        if (nk > 1) issue(1, g1);
+        commit(0, g0);
+        __syncthreads();
+        auto step = [&](int kt, Regs& fresh, Regs& next) {
+            if (kt + 2 < nk) issue(kt + 2, fresh);
+            body(kt);
+            if (kt + 1 < nk) commit((kt + 1) & 1, next);
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, g0, g1);
+            if (kt + 1 < nk) step(kt + 1, g1, g0);
+        }
+    } else {
+        Regs g;
+        issue(0, g);
+        commit(0, g);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue(kt + 1, g);
+            body(kt);
+            if (kt + 1 < nk) commit((kt + 1) & 1, g);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace gemmx3

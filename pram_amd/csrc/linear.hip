@@ -259,6 +259,57 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
     linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
 }
 
+// Both operands as split planes (gemm_core_x3.h::mainloop_planes): A = [a0 | a1] with planes (a0h, a0l) [m][lda0] and, for the
+// concatenated input, (a1h, a1l) [m][lda1] — halves, written by the producing kernels' epilogues.
+struct PlaneArgs {
+    const _Float16* a0h; const _Float16* a0l; int lda0;
+    const _Float16* a1h; const _Float16* a1l; int lda1;
+};
+
+template <int MI, int WN>
+__global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3p_kernel(LinArgs p, PlaneArgs a, const _Float16* __restrict__ wh,
+                                                                    const _Float16* __restrict__ wl, float inv) {
+    using namespace gemmx3;
+    using C = Cfg<MI, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    __shared__ Smem<MI, WN> smem;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int K = p.k0 + p.k1;
+    const int tid = threadIdx.x;
+    const int srow = tid >> 2, ssl = tid & 3;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int mlast = p.m - 1, nlast = p.n - 1;
+    size_t aoff0[BM / 64], aoff1[BM / 64], boff[BN / 64];
+#pragma unroll
+    for (int pp = 0; pp < BM / 64; ++pp) {
+        const size_t rc = (size_t)min(row0 + srow + 64 * pp, mlast);
+        aoff0[pp] = rc * a.lda0 + ssl * 8;
+        aoff1[pp] = rc * a.lda1 + ssl * 8;
+    }
+#pragma unroll
+    for (int pp = 0; pp < BN / 64; ++pp) boff[pp] = (size_t)min(col0 + srow + 64 * pp, nlast) * K + ssl * 8;
+    auto la = [&](int pp, int kt, int plane) -> uint4 {
+        const int k = kt * BK;
+        if (k >= p.k0 && p.k1 > 0)                                       // wave-uniform: k0 % 32 == 0
+            return *reinterpret_cast<const uint4*>((plane ? a.a1l : a.a1h) + aoff1[pp] + (k - p.k0));
+        return *reinterpret_cast<const uint4*>((plane ? a.a0l : a.a0h) + aoff0[pp] + k);
+    };
+    auto oka = [&](int pp, int kt) -> bool { return (row0 + srow + 64 * pp) < p.m; };
+    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + srow + 64 * pp) < p.n; };
+    f32x16 acc[MI][2];
+    mainloop_planes<MI, WN>(smem, la, oka, lb, okb, K / BK, acc);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
+    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
+}
+
 // ---------------------------------------------------------------- LayerNorm + GELU
 // One wave per row; the row (<= 1024 floats) lives in registers, mean then centred variance
 // (two-pass, like torch's RowwiseMoments result to fp32 rounding), exact erf GELU.
@@ -349,7 +400,45 @@ void launch_linear_x3_t(LinArgs& p, const _Float16* wh, const _Float16* wl, floa
     hipLaunchKernelGGL((linear_x3_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
 }
 
+template <int MI, int WN>
+void launch_linear_x3p_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+    using C = gemmx3::Cfg<MI, WN>;
+    p.tiles_m = cdiv(p.m, C::BM);
+    p.tiles_n = cdiv(p.n, C::BN);
+    hipLaunchKernelGGL((linear_x3p_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, a, wh, wl, inv);
+}
+
 }  // namespace
+
+/* pram_linear_x3_f32 with the activations already split ("planes": value * 16 = hi + lo, two fp16 matrices [m][lda] written
+   by pram_linear_x3_f32 / pram_attention_x3_f32 / pram_layernorm_gelu_x3): the main loop stages both operands with plain
+   16-byte copies.  K = k0 + k1 and k0 must be multiples of 32; lda multiples of 8. */
+extern "C" int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda0, int k0, const void* a1_hi, const void* a1_lo,
+                                   int lda1, int k1, const void* w_hi, const void* w_lo, float w_scale, const float* bias,
+                                   const float* residual, int ldr, float* out, int ldo, void* out_hi, void* out_lo, int ldo16,
+                                   int m, int n, float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                                   void* stream) {
+    PRAM_REQUIRE(a0_hi && a0_lo && w_hi && w_lo && (out || (out_hi && out_lo)), "pram_linear_x3p_f32: null pointer");
+    PRAM_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), "pram_linear_x3p_f32: the split output needs both planes");
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0 && w_scale > 0.f, "pram_linear_x3p_f32: bad sizes");
+    PRAM_REQUIRE(k0 % 32 == 0 && k1 % 32 == 0 && lda0 % 8 == 0, "pram_linear_x3p_f32: k0, k1 must be multiples of 32, lda of 8");
+    PRAM_REQUIRE(k1 == 0 || (a1_hi && a1_lo && lda1 % 8 == 0), "pram_linear_x3p_f32: second segment needs both planes");
+    if (flags & PRAM_LIN_ROTARY)
+        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_x3p_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
+    if (m == 0) return PRAM_OK;
+    LinArgs p{nullptr, lda0, k0, nullptr, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE};
+    PlaneArgs a{(const _Float16*)a0_hi, (const _Float16*)a0_lo, lda0, (const _Float16*)a1_hi, (const _Float16*)a1_lo, lda1};
+    int mi, wn;
+    gemm::choose_tile(m, n, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* wh = (const _Float16*)w_hi;
+    const _Float16* wl = (const _Float16*)w_lo;
+    const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    if (wn == 2) { if (mi == 2) launch_linear_x3p_t<2, 2>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 2>(p, a, wh, wl, inv, st); }
+    else         { if (mi == 2) launch_linear_x3p_t<2, 1>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 1>(p, a, wh, wl, inv, st); }
+    return pram_launch_status("pram_linear_x3p_f32");
+}
 
 extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
                                   const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,

@@ -112,6 +112,40 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def linear_planes(x, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2=None, residual: Optional[torch.Tensor] = None,
+                  alpha: float = 1.0, rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, out: str = "f32"):
+    """linear() on the split-fp16 path with the activations ALREADY split: x (and x2) are (hi, lo) pairs of fp16 2-D views
+    (value * 16 = hi + lo) written by a producing kernel's epilogue.  out: "f32" -> fp32 tensor; "planes" -> (hi, lo) planes of
+    the result * 16; "both" -> (fp32, (hi, lo))."""
+    L = _lib.load()
+    xh, xl = x
+    assert xh.dtype == torch.float16 and xh.dim() == 2 and xh.stride(1) == 1 and xh.stride(0) == xl.stride(0)
+    m, k0 = xh.shape
+    k1 = 0
+    if x2 is not None:
+        assert x2[0].shape[0] == m and x2[0].stride(1) == 1 and x2[0].stride(0) == x2[1].stride(0)
+        k1 = x2[0].shape[1]
+    w = w.contiguous()
+    n = w.shape[0]
+    assert w.shape[1] == k0 + k1 and k0 % 32 == 0 and k1 % 32 == 0
+    o32 = torch.empty(m, n, device=xh.device, dtype=torch.float32) if out in ("f32", "both") else None
+    planes = torch.empty(2, m, n, device=xh.device, dtype=torch.float16) if out in ("planes", "both") else None
+    flags, rc, rs, rcols = 0, None, None, 0
+    if rotary is not None:
+        rc, rs, rcols = rotary
+        flags = 1
+    if residual is not None:
+        residual = residual.contiguous()
+    if m:
+        wh, wl, ws = split_weight(w)
+        _lib.check(L.pram_linear_x3p_f32(_p(xh), _p(xl), xh.stride(0), k0, _p(x2[0]) if k1 else None, _p(x2[1]) if k1 else None,
+                                         x2[0].stride(0) if k1 else 0, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n, _p(o32), n,
+                                         _p(planes[0]) if planes is not None else None, _p(planes[1]) if planes is not None else None,
+                                         n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()), "pram_linear_x3p_f32")
+    pl = None if planes is None else (planes[0], planes[1])
+    return o32 if out == "f32" else (pl if out == "planes" else (o32, pl))
+
+
 def bgemm_nt(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, ldc: Optional[int] = None) -> torch.Tensor:
     """c[z] = alpha * a[z] @ b[z].T ; a [B,M,K], b [B,N,K] -> c [B,M,ldc] (view [:, :, :N] is the result)."""
     L = _lib.load()
