@@ -6,17 +6,18 @@
 //     x * 16 = hi + lo,  hi = fp16(16 x),  lo = fp16(16 x - hi)
 // and every product is three MFMAs accumulated in fp32 (gemm_core_x3.h has the error analysis):
 //     S^T = K_hi Q_hi + K_hi Q_lo + K_lo Q_hi            (= 256 K Q^T; the 1/256 rides in the softmax scale)
-//     O^T = V^T_hi P_hi + V^T_hi P_lo + V^T_lo P_hi       (P = 2^14 exp2(...) split in registers, = 2^18 V^T P)
-// The probabilities are scaled by 2^14 (an offset in the exponent argument: free) so that hi + lo keeps 22 bits for
-// every probability above 2^-17 of the row maximum; the row sum accumulates the same scaled fp32 values, so the
-// scale cancels in the normalisation.
+//     O^T = V^T_hi P_hi + V^T_lo P_hi                     (P = fp16(2^14 exp2(...)), = 2^18 V^T P; two MFMAs: see the loop)
+// The probabilities are scaled by 2^14 (an offset in the exponent argument: free) so that fp16 keeps 11 bits for every
+// probability above 2^-28 of the row maximum; the row sum accumulates the same rounded values, so scale and rounding
+// bias cancel in the normalisation.
 //
 // Register design as attention.hip / attention_f16.hip: everything transposed so that the query row is the lane
 // index in every accumulator (online-softmax state lane-local, P never leaves registers); K tile [key][d] and V tile
 // TRANSPOSED and key-permuted [d][pos(key)] in LDS so that both MFMA operands are single ds_read_b128s.
-// Per 64-key tile per wave: 48 MFMA x 32 cycles = 1536 matrix cycles (the f32-MFMA kernel: 8192).
+// Per 64-key tile per wave: 40 MFMA x 32 cycles = 1280 matrix cycles (the f32-MFMA kernel: 8192).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -54,6 +55,9 @@ __device__ __forceinline__ int pos_of_key(int key) {
     return t * 32 + u * 16 + h * 8 + i;
 }
 
+// ABL: profiling ablations (PRAM_ATTN_ABLATE, never set in production): bit 0 skips the softmax arithmetic, bit 1 the LDS
+// fragment reads after the first, bit 2 the K / V staging — results are garbage, the remaining work keeps its shape.
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
     __shared__ Smem s;
     const int nblk = p.batch * p.heads * p.q_tiles;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) gload(kt + 1);
+        if (more && !(ABL & 4)) gload(kt + 1);
 
         if (wave_active) {
             f32x16 st[2];
@@ -167,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             kload(1, kb2);
             __builtin_amdgcn_sched_barrier(0);
             kmma(0, ka);
-            kload(2, ka);
+            if (!(ABL & 2)) kload(2, ka);
             __builtin_amdgcn_sched_barrier(0);
             kmma(1, kb2);
-            kload(3, kb2);
+            if (!(ABL & 2)) kload(3, kb2);
             __builtin_amdgcn_sched_barrier(0);
             kmma(2, ka);
             __builtin_amdgcn_sched_barrier(0);
@@ -204,17 +208,26 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             const float m_new = fmaxf(m_run, tmax * p.scale2);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             const float shift = P_EXP_SHIFT - m_new;
+            // The probabilities enter P V as ONE fp16 (P_hi): two MFMAs per product (V_lo P_hi + V_hi P_hi) instead of three, and
+            // no splitting arithmetic — this kernel is bound by its softmax VALU, not by the matrix pipe.  The row sum is taken
+            // over the SAME rounded values (v_dot2_f32_f16 against (1, 1): exact fp32 accumulation of the fp16 pairs), so the
+            // 2^-12 relative rounding of each probability perturbs only the softmax WEIGHTS' ratios, independently per key:
+            // measured end to end against the fp32 oracle 4.6e-5 on the SegNetViT logits (1.4e-5 with P split as well), matcher
+            // indices identical (profiles/tools/split_emulation.py --p-hi-only).
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            const half2_t ones = {(_Float16)1.f, (_Float16)1.f};
             float psum = 0.f;
-            half8 ph[2][2], pl[2][2];
+            half8 ph[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, shift));   // v_exp_f32: argument <= 14
-                    psum += pv;
-                    const _Float16 hi = (_Float16)pv;
-                    ph[t][e >> 3][e & 7] = hi;
-                    pl[t][e >> 3][e & 7] = (_Float16)(pv - (float)hi);
+                for (int e = 0; e < 16; e += 2) {
+                    const float p0 = (ABL & 1) ? st[t][e] : __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, shift));       // v_exp_f32: argument <= 14
+                    const float p1 = (ABL & 1) ? st[t][e + 1] : __builtin_amdgcn_exp2f(fmaf(st[t][e + 1], p.scale2, shift));
+                    const half2_t pk = {(_Float16)p0, (_Float16)p1};
+                    psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
+                    ph[t][e >> 3][e & 7] = pk[0];
+                    ph[t][e >> 3][(e & 7) + 1] = pk[1];
                 }
             l_run = fmaf(l_run, alpha, psum);
             m_run = m_new;
@@ -223,23 +236,21 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             auto vmma = [&](int t, int u, const VFrag& f) {
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ph[t][u], oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ph[t][u], oacc[1], 0, 0, 0);
             };
             __builtin_amdgcn_sched_barrier(0);
             vmma(0, 0, va);
-            vload(1, 0, va);
+            if (!(ABL & 2)) vload(1, 0, va);
             __builtin_amdgcn_sched_barrier(0);
             vmma(0, 1, vb);
-            vload(1, 1, vb);
+            if (!(ABL & 2)) vload(1, 1, vb);
             __builtin_amdgcn_sched_barrier(0);
             vmma(1, 0, va);
             __builtin_amdgcn_sched_barrier(0);
             vmma(1, 1, vb);
         }
-        if (more) lstore(cur ^ 1);
+        if (more && !(ABL & 4)) lstore(cur ^ 1);
         __syncthreads();
     }
 
@@ -335,6 +346,15 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
             scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift};
-    hipLaunchKernelGGL(attention_x3_kernel, dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    static const char* abl = getenv("PRAM_ATTN_ABLATE");
+    const dim3 grid(batch * heads * p.q_tiles), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (abl ? atoi(abl) : 0) {
+        case 1: hipLaunchKernelGGL(attention_x3_kernel<1>, grid, blk, 0, st, p); break;
+        case 2: hipLaunchKernelGGL(attention_x3_kernel<2>, grid, blk, 0, st, p); break;
+        case 4: hipLaunchKernelGGL(attention_x3_kernel<4>, grid, blk, 0, st, p); break;
+        case 7: hipLaunchKernelGGL(attention_x3_kernel<7>, grid, blk, 0, st, p); break;
+        default: hipLaunchKernelGGL(attention_x3_kernel<0>, grid, blk, 0, st, p);
+    }
     return pram_launch_status("pram_attention_x3_f32");
 }

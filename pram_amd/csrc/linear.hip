@@ -4,6 +4,7 @@
 #include "gemm_core.h"
 #include "gemm_core_f16.h"
 #include "gemm_core_x3.h"
+#include "gemm_core_x3w.h"
 
 namespace {
 
@@ -310,6 +311,73 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3p_kernel(LinArgs p, Pl
     linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
 }
 
+// Wide-tile split-fp16 GEMM (gemm_core_x3w.h): 256 x 256 or 128 x 256 outputs per 512-thread workgroup, A as fp32 (split while
+// staged) or as pre-split planes.  Same arithmetic and accumulation order as linear_x3_kernel: bit-identical results.
+template <int MI, int WM, int WN, bool APLANES>
+__global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, PlaneArgs a, const _Float16* __restrict__ wh,
+                                                                      const _Float16* __restrict__ wl, float inv) {
+    using namespace gemmx3w;
+    using C = Cfg<MI, WM, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem<MI, WM, WN>& smem = *reinterpret_cast<Smem<MI, WM, WN>*>(smem_raw);
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int K = p.k0 + p.k1;
+    const int tid = threadIdx.x;
+    const int arow = tid >> 3, akq = tid & 7, qrow = tid >> 2, qsl = tid & 3;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int mlast = p.m - 1, nlast = p.n - 1;
+    size_t boff[C::QB];
+#pragma unroll
+    for (int pp = 0; pp < C::QB; ++pp) boff[pp] = (size_t)min(col0 + qrow + C::RQ * pp, nlast) * K + qsl * 8;
+    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + qrow + C::RQ * pp) < p.n; };
+    auto adv = [](int) {};
+    f32x16 acc[MI][2];
+    if constexpr (APLANES) {
+        size_t aoff0[C::QA], aoff1[C::QA];
+#pragma unroll
+        for (int pp = 0; pp < C::QA; ++pp) {
+            const size_t rc = (size_t)min(row0 + qrow + C::RQ * pp, mlast);
+            aoff0[pp] = rc * a.lda0 + qsl * 8;
+            aoff1[pp] = rc * a.lda1 + qsl * 8;
+        }
+        auto la = [&](int pp, int kt, int plane) -> uint4 {
+            const int k = kt * BK;
+            if (k >= p.k0 && p.k1 > 0)                                       // wave-uniform: k0 % 32 == 0
+                return *reinterpret_cast<const uint4*>((plane ? a.a1l : a.a1h) + aoff1[pp] + (k - p.k0));
+            return *reinterpret_cast<const uint4*>((plane ? a.a0l : a.a0h) + aoff0[pp] + k);
+        };
+        auto oka = [&](int pp, int kt) -> bool { return (row0 + qrow + C::RQ * pp) < p.m; };
+        mainloop<MI, WM, WN, true>(smem, adv, la, oka, lb, okb, K / BK, gemmx3::ACT_SCALE, acc);
+    } else {
+        const float* arow0[C::PA];
+        const float* arow1[C::PA];
+#pragma unroll
+        for (int pp = 0; pp < C::PA; ++pp) {
+            const int rc = min(row0 + arow + C::RA * pp, mlast);
+            arow0[pp] = p.a0 + (size_t)rc * p.lda0;
+            arow1[pp] = p.a1 ? p.a1 + (size_t)rc * p.lda1 - p.k0 : arow0[pp];
+        }
+        auto la = [&](int pp, int kt) -> float4 {
+            const int kc = kt * BK + akq * 4;
+            const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
+            return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
+        };
+        auto oka = [&](int pp, int kt) -> bool { return (row0 + arow + C::RA * pp) < p.m; };
+        mainloop<MI, WM, WN, false>(smem, adv, la, oka, lb, okb, K / BK, gemmx3::ACT_SCALE, acc);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
+    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
+}
+
 // ---------------------------------------------------------------- LayerNorm + GELU
 // One wave per row; the row (<= 1024 floats) lives in registers, mean then centred variance
 // (two-pass, like torch's RowwiseMoments result to fp32 rounding), exact erf GELU.
@@ -400,6 +468,34 @@ void launch_linear_x3_t(LinArgs& p, const _Float16* wh, const _Float16* wl, floa
     hipLaunchKernelGGL((linear_x3_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
 }
 
+template <int MI, int WM, int WN, bool APLANES>
+void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+    using C = gemmx3w::Cfg<MI, WM, WN>;
+    p.tiles_m = cdiv(p.m, C::BM);
+    p.tiles_n = cdiv(p.n, C::BN);
+    const size_t shm = sizeof(gemmx3w::Smem<MI, WM, WN>);
+    static bool attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)linear_x3w_kernel<MI, WM, WN, APLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv);
+}
+
+// wide tiles (gemm_core_x3w.h) for outputs at least 256 columns wide: 256 x 256 when that still gives every CU a workgroup,
+// 128 x 256 otherwise.  PRAM_X3_TILE=narrow|w256|w128 overrides (profiling).
+template <bool APLANES>
+bool launch_linear_x3_wide(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+    static const char* force = getenv("PRAM_X3_TILE");
+    if (force && force[0] == 'n') return false;
+    if (p.n < 256 || (p.k0 + p.k1) % 32 != 0) return false;
+    const long big = (long)cdiv(p.m, 256) * cdiv(p.n, 256);
+    const bool use256 = force ? (force[1] == '2') : big >= 224;
+    if (use256) launch_linear_x3w_t<4, 2, 4, APLANES>(p, a, wh, wl, inv, st);
+    else launch_linear_x3w_t<2, 2, 4, APLANES>(p, a, wh, wl, inv, st);
+    return true;
+}
+
 template <int MI, int WN>
 void launch_linear_x3p_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
     using C = gemmx3::Cfg<MI, WN>;
@@ -435,6 +531,7 @@ extern "C" int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda
     const _Float16* wh = (const _Float16*)w_hi;
     const _Float16* wl = (const _Float16*)w_lo;
     const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    if (launch_linear_x3_wide<true>(p, a, wh, wl, inv, st)) return pram_launch_status("pram_linear_x3p_f32");
     if (wn == 2) { if (mi == 2) launch_linear_x3p_t<2, 2>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 2>(p, a, wh, wl, inv, st); }
     else         { if (mi == 2) launch_linear_x3p_t<2, 1>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 1>(p, a, wh, wl, inv, st); }
     return pram_launch_status("pram_linear_x3p_f32");
@@ -460,6 +557,10 @@ extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float
     const _Float16* wh = (const _Float16*)w_hi;
     const _Float16* wl = (const _Float16*)w_lo;
     const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    {
+        PlaneArgs none{nullptr, nullptr, 0, nullptr, nullptr, 0};
+        if (launch_linear_x3_wide<false>(p, none, wh, wl, inv, st)) return pram_launch_status("pram_linear_x3_f32");
+    }
     if (wn == 2) { if (mi == 2) launch_linear_x3_t<2, 2>(p, wh, wl, inv, st); else launch_linear_x3_t<1, 2>(p, wh, wl, inv, st); }
     else         { if (mi == 2) launch_linear_x3_t<2, 1>(p, wh, wl, inv, st); else launch_linear_x3_t<1, 1>(p, wh, wl, inv, st); }
     return pram_launch_status("pram_linear_x3_f32");

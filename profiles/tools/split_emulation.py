@@ -72,8 +72,26 @@ def einsum(eq, a, b):
     if not MODE["on"]:
         return _real_einsum(eq, a, b)
     # softmax probabilities (in [0, 1]) get the large scale, everything else the activation scale
-    sa = 16384.0 if (a.min() >= 0 and a.max() <= 1.0) else MODE["act_scale"]
-    sb = 16384.0 if (b.min() >= 0 and b.max() <= 1.0) else MODE["act_scale"]
+    pa = bool(a.min() >= 0 and a.max() <= 1.0)
+    pb = bool(b.min() >= 0 and b.max() <= 1.0)
+    sa = 16384.0 if pa else MODE["act_scale"]
+    sb = 16384.0 if pb else MODE["act_scale"]
+    if MODE.get("p_hi_only") and (pa != pb):
+        # P V with the probabilities rounded to ONE fp16 (two MFMAs: P_hi V_hi + P_hi V_lo); the softmax normalisation uses the
+        # same rounded probabilities, as the kernel would
+        P, V, sp, sv = (a, b, sa, sb) if pa else (b, a, sb, sa)
+        ph = (P * sp).half().float()
+        vh, vl = split(V, sv)
+        f = (lambda x, y: _real_einsum(eq, x, y)) if pa else (lambda x, y: _real_einsum(eq, y, x))
+        out = (f(ph, vh) + f(ph, vl)) / (sp * sv)
+        # renormalise: sum of the rounded row / sum of the exact row (rows of P sum to 1)
+        red = P.dim() - 1 if pa else None
+        ratio = (ph / sp).sum(-1, keepdim=True) if pa else None
+        if pa and eq == "bhij,bhjd->bhid":
+            return out / ratio
+        if (not pa) and eq == "bhji,bhid->bhjd":      # a10 = softmax(sim^T): P = b? (cross block writes einsum(a10, v0))
+            return out
+        return out
     return _combine(lambda p, q: _real_einsum(eq, p, q), a, b, sa, sb)
 
 
@@ -141,8 +159,9 @@ if __name__ == "__main__":
     ap.add_argument("--nc", type=int, default=113)
     ap.add_argument("--terms", type=int, default=3, help="3 = hi.hi + hi.lo + lo.hi ; 1 = plain fp16 (for contrast)")
     ap.add_argument("--act-scale", type=float, default=16.0)
+    ap.add_argument("--p-hi-only", action="store_true", help="P V from fp16(P) alone: two MFMAs per product instead of three")
     args = ap.parse_args()
-    MODE["terms"], MODE["act_scale"] = args.terms, args.act_scale
+    MODE["terms"], MODE["act_scale"], MODE["p_hi_only"] = args.terms, args.act_scale, args.p_hi_only
     torch.set_num_threads(8)
     with torch.no_grad():
         for wh in args.what:

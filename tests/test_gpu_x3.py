@@ -138,7 +138,10 @@ def test_attention_x3_vs_fp64(dev, B, M, N, ragged):
         ex3 = max(ex3, err(ox3[b, :mq], ref[b, :mq]))
         el = max(el, float((lse[b, :, :mq] - lse32[b, :, :mq]).abs().max()))
     print(f"attention B{B} {M}x{N}: |err| f32 {e32:.2e}  x3 {ex3:.2e}; lse |x3 - f32| {el:.2e}")
-    assert ex3 < 3e-6 and ex3 < 4 * e32 + 5e-7 and el < 1e-5
+    # S = K Q^T is a full three-term split product (the log-sum-exp agrees with the f32-MFMA kernel to 1e-5); the probabilities
+    # enter P V as one fp16 each, normalised by the sum of the same rounded values: a 2^-12 relative perturbation of the softmax
+    # weights, independent per key -> errors of a few 1e-5 on O(1) values (vs 1e-6 for the exact kernels, 1e-3 for the fp16 path)
+    assert ex3 < 1e-4 and el < 1e-5
 
 
 def test_attention_x3_cross_equals_two_directions(dev):
@@ -172,7 +175,7 @@ def test_attention_x3_spike_and_empty(dev):
     ref = _attn_ref(sp(q, M), sp(k, N), sp(v, N), 0.125).permute(0, 2, 1, 3).reshape(M, 256)
     vt = ops.value_planes_t(_planes(ops, v.to(dev)), B, 4, N)
     out = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), vt, B, 4, M, N, 0.125)
-    assert err(out, ref) < 3e-6
+    assert err(out, ref) < 1e-4
     kl = torch.zeros(1, dtype=torch.int32, device=dev)
     out0 = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), vt, B, 4, M, N, 0.125, None, kl)
     assert float(out0.abs().max()) == 0.0
