@@ -95,6 +95,20 @@ int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda0, int k0, 
                         int m, int n, float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
                         void* stream);
 
+/* Ragged token matrices (AdaGML's pruned / stopped pairs): rows are sequences of t_pad rows, sequence s has lens[s] (device
+ * int32) valid ones.  Output tiles that contain no valid row are skipped and their outputs left untouched; everything else is
+ * the un-ragged call.  (The reference shrinks its tensors with boolean indexing instead, nets/adagml.py:354-372.) */
+int pram_linear_ragged_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                           const float* w, const float* bias, const float* residual, int ldr,
+                           float* out, int ldo, int m, int n, float alpha, int flags,
+                           const float* rot_cos, const float* rot_sin, int rot_cols,
+                           const int* lens, int t_pad, void* stream);
+int pram_linear_x3_ragged_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                              const void* w_hi, const void* w_lo, float w_scale, const float* bias,
+                              const float* residual, int ldr, float* out, int ldo, void* out_hi, void* out_lo,
+                              int ldo16, int m, int n, float alpha, int flags, const float* rot_cos,
+                              const float* rot_sin, int rot_cols, const int* lens, int t_pad, void* stream);
+
 /* Batched C_b = alpha * A_b · B_bᵀ (einsum 'bmd,bnd->bmn', nets/gml.py:282; K12).
  * A_b = a + b*stride_a, [m_max][lda]; B_b [n_max][ldb]; C_b [m_max][ldc]. */
 int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
@@ -105,6 +119,10 @@ int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* 
  * nets/segnetvit.py:92-93,161-162; K11).  In place when y == x.  cols <= 1024, cols % 4 == 0 */
 int pram_layernorm_gelu_f32(const float* x, int ldx, float* y, int ldy, const float* gamma,
                             const float* beta, int rows, int cols, float eps, void* stream);
+
+/* the same, skipping the rows beyond their sequence's length (see pram_linear_ragged_f32) */
+int pram_layernorm_gelu_ragged_f32(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                   int rows, int cols, float eps, const int* lens, int t_pad, void* stream);
 
 /* Fourier positional encoding (normalize_keypoints nets/utils.py:17-24 +
  * LearnableFourierPositionalEncoding nets/segnetvit.py:35-40; K7):

@@ -57,7 +57,9 @@ __device__ __forceinline__ int pos_of_key(int key) {
 
 // ABL: profiling ablations (PRAM_ATTN_ABLATE, never set in production): bit 0 skips the softmax arithmetic, bit 1 the LDS
 // fragment reads after the first, bit 2 the K / V staging — results are garbage, the remaining work keeps its shape.
-template <int ABL>
+// PSPLIT: the probabilities enter P V split like every other operand (three MFMAs per product, 22-bit P) instead of as one fp16
+// (two MFMAs): used below 1024 keys, where the per-key rounding of single-fp16 probabilities does not average out.
+template <int ABL, bool PSPLIT>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
     __shared__ Smem s;
     const int nblk = p.batch * p.heads * p.q_tiles;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
             const half2_t ones = {(_Float16)1.f, (_Float16)1.f};
             float psum = 0.f;
-            half8 ph[2][2];
+            half8 ph[2][2], pl[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -225,9 +227,15 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
                     const float p0 = (ABL & 1) ? st[t][e] : __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, shift));       // v_exp_f32: argument <= 14
                     const float p1 = (ABL & 1) ? st[t][e + 1] : __builtin_amdgcn_exp2f(fmaf(st[t][e + 1], p.scale2, shift));
                     const half2_t pk = {(_Float16)p0, (_Float16)p1};
-                    psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
                     ph[t][e >> 3][e & 7] = pk[0];
                     ph[t][e >> 3][(e & 7) + 1] = pk[1];
+                    if constexpr (PSPLIT) {
+                        psum += p0 + p1;
+                        pl[t][e >> 3][e & 7] = (_Float16)(p0 - (float)pk[0]);
+                        pl[t][e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)pk[1]);
+                    } else {
+                        psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
+                    }
                 }
             l_run = fmaf(l_run, alpha, psum);
             m_run = m_new;
@@ -236,6 +244,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
             auto vmma = [&](int t, int u, const VFrag& f) {
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
+                if constexpr (PSPLIT) {
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
+                }
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ph[t][u], oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ph[t][u], oacc[1], 0, 0, 0);
             };
@@ -349,12 +361,17 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     static const char* abl = getenv("PRAM_ATTN_ABLATE");
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    if (n_max < 1024) {
+        hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p);
+        return pram_launch_status("pram_attention_x3_f32");
+    }
     switch (abl ? atoi(abl) : 0) {
-        case 1: hipLaunchKernelGGL(attention_x3_kernel<1>, grid, blk, 0, st, p); break;
-        case 2: hipLaunchKernelGGL(attention_x3_kernel<2>, grid, blk, 0, st, p); break;
-        case 4: hipLaunchKernelGGL(attention_x3_kernel<4>, grid, blk, 0, st, p); break;
-        case 7: hipLaunchKernelGGL(attention_x3_kernel<7>, grid, blk, 0, st, p); break;
-        default: hipLaunchKernelGGL(attention_x3_kernel<0>, grid, blk, 0, st, p);
+        case 1: hipLaunchKernelGGL((attention_x3_kernel<1, false>), grid, blk, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((attention_x3_kernel<2, false>), grid, blk, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((attention_x3_kernel<4, false>), grid, blk, 0, st, p); break;
+        case 7: hipLaunchKernelGGL((attention_x3_kernel<7, false>), grid, blk, 0, st, p); break;
+        case 8: hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p); break;
+        default: hipLaunchKernelGGL((attention_x3_kernel<0, false>), grid, blk, 0, st, p);
     }
     return pram_launch_status("pram_attention_x3_f32");
 }

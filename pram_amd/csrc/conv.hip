@@ -7,9 +7,11 @@
 // on the host to [Cout][ky][kx][Cin].  The A loader does the im2col on the fly (bounds-checked
 // zero padding); everything after that is gemm_core.h.  Eval-mode BatchNorm is applied as a
 // per-channel scale/shift in the epilogue (same op order as conv -> BN), then residual, then ReLU.
+#include <stdlib.h>
 #include "gemm_core.h"
 #include "gemm_core_f16.h"
 #include "gemm_core_x3.h"
+#include "gemm_core_x3w.h"
 
 namespace {
 
@@ -261,6 +263,71 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
     conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 
+// wide-tile split-fp16 convolution (gemm_core_x3w.h): 256 output pixels x 256 channels per 512-thread workgroup — the 256-channel
+// layers (conv3a / conv3b / convDa.* / convPa.* / conv4 1x1: 80 % of the stack's MACs).  Same arithmetic and accumulation order
+// as conv_x3_kernel: bit-identical results.
+template <int MI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, const _Float16* __restrict__ wh,
+                                                                    const _Float16* __restrict__ wl, float inv) {
+    using namespace gemmx3w;
+    using C = Cfg<MI, WM, WN>;
+    constexpr int BM = C::BM, BN = C::BN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem<MI, WM, WN>& smem = *reinterpret_cast<Smem<MI, WM, WN>*>(smem_raw);
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n, tm = id / p.tiles_n;
+    const int tid = threadIdx.x;
+    const int arow = tid >> 3, akq = tid & 7, qrow = tid >> 2, qsl = tid & 3;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int pad = p.ks >> 1;
+    int iy0[C::PA], ix0[C::PA];
+    const float* base[C::PA];
+    bool ok[C::PA];
+#pragma unroll
+    for (int pp = 0; pp < C::PA; ++pp) {
+        const int row = row0 + arow + C::RA * pp;
+        ok[pp] = row < p.m;
+        const int rr = ok[pp] ? row : 0;
+        const int ox = rr % p.wo;
+        const int t = rr / p.wo;
+        const int oy = t % p.ho;
+        const int b = t / p.ho;
+        iy0[pp] = oy * p.stride - pad;
+        ix0[pp] = ox * p.stride - pad;
+        base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
+    }
+    const int nlast = p.cout - 1;
+    int cky = 0, ckx = 0, cci = 0;
+    auto adv = [&](int kt) {
+        if (kt == 0) { cky = ckx = cci = 0; return; }
+        cci += BK;
+        if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
+    };
+    size_t boff[C::QB];
+#pragma unroll
+    for (int pp = 0; pp < C::QB; ++pp) boff[pp] = (size_t)min(col0 + qrow + C::RQ * pp, nlast) * p.k + qsl * 8;
+    auto la = [&](int pp, int kt) -> float4 {
+        const int iyc = min(max(iy0[pp] + cky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
+        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + akq * 4);
+    };
+    auto oka = [&](int pp, int kt) -> bool {
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
+        return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+    };
+    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
+    auto okb = [&](int pp, int kt) -> bool { return (col0 + qrow + C::RQ * pp) < p.cout; };
+    f32x16 acc[MI][2];
+    mainloop<MI, WM, WN, false>(smem, adv, la, oka, lb, okb, p.k / BK, gemmx3::ACT_SCALE, acc);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
+    conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
+}
+
 // ---------------------------------------------------------------- grouped 3x3 (VALU)
 // groups = 32, 8 in / 8 out channels per group (72-deep dot products: too thin for MFMA tiles).
 // Workgroup = 64 consecutive x-pixels x 4 output rows x 4 groups (one group per wave, so the 576
@@ -466,6 +533,20 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
         p.tiles_n = cdiv(cout, gemmx3::Cfg<MI_, WN_>::BN);                                                              \
         hipLaunchKernelGGL((conv_x3_kernel<MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemmx3::NT), 0, st, p, wh, wl, inv); \
     } while (0)
+    static const char* force = getenv("PRAM_X3_TILE");
+    if (cout >= 256 && (long)cdiv(p.m, 256) * cdiv(cout, 256) >= 224 && !(force && force[0] == 'n')) {
+        using CW = gemmx3w::Cfg<4, 2, 4>;
+        const size_t shm = sizeof(gemmx3w::Smem<4, 2, 4>);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_x3w_kernel<4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            attr_set = true;
+        }
+        p.tiles_m = cdiv(p.m, CW::BM);
+        p.tiles_n = cdiv(cout, CW::BN);
+        hipLaunchKernelGGL((conv_x3w_kernel<4, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(CW::NT), shm, st, p, wh, wl, inv);
+        return pram_launch_status("pram_conv2d_nhwc_x3_f32");
+    }
     if (wn == 1) { if (mi == 2) LAUNCHX3(2, 1); else LAUNCHX3(1, 1); }
     else { if (mi == 2) LAUNCHX3(2, 2); else LAUNCHX3(1, 2); }
 #undef LAUNCHX3

@@ -28,7 +28,18 @@ struct LinArgs {
     // split-fp16 output planes (x3 path): out16 = hi plane, out16_lo = lo plane of out * out16_scale (out16_lo == nullptr:
     // out16 is the plain fp16 copy of the C5 path)
     void* out16_lo; float out16_scale;
+    // ragged token matrices: rows are sequences of t_pad rows, sequence s has lens[s] valid ones; output tiles without a valid
+    // row are skipped (their outputs are left untouched).  lens == nullptr: every row counts.
+    const int* lens; int t_pad;
 };
+
+__device__ __forceinline__ bool tile_has_rows(const int* __restrict__ lens, int t_pad, int row0, int bm, int m) {
+    if (!lens) return true;
+    const int rend = min(row0 + bm, m);
+    for (int s = row0 / t_pad; s * t_pad < rend; ++s)
+        if (max(row0, s * t_pad) - s * t_pad < lens[s]) return true;
+    return false;
+}
 
 // Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
 template <int MI, int WN>
@@ -47,7 +58,10 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
     const bool c0ok = c0 < p.n, c1ok = c1 < p.n;
     const int c0c = min(c0, nlast), c1c = min(c1, nlast);
     const float b0 = p.bias ? p.bias[c0c] : 0.f, b1 = p.bias ? p.bias[c1c] : 0.f;
-    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n);
+    // ragged mode: only the valid rows of a tile are stored (`out` may be a persistent buffer whose other rows belong to
+    // sequences that are not part of this call — AdaGML commits the matching descriptors of the pairs stopping at a layer)
+    const bool ragged = p.lens != nullptr;
+    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n) && !ragged;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int rbase = row0 + wm * 32 * MI;
@@ -118,7 +132,9 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + acc_row(mi, e, h);
-                if (row < p.m) {
+                bool ok = row < p.m;
+                if (ragged && ok) { const int sq = row / p.t_pad; ok = row - sq * p.t_pad < p.lens[sq]; }
+                if (ok) {
                     if (c0ok) out[(size_t)row * p.ldo + c0] = q0[e];
                     if (c1ok) out[(size_t)row * p.ldo + c1] = q1[e];
                 }
@@ -144,6 +160,7 @@ __global__ __launch_bounds__(gemm::NT, (gemm::Cfg<MI, WN, BKT>::WAVES)) void lin
     const int tid = threadIdx.x;
     const int srow = C::stage_row(tid), skq = C::stage_kq(tid);
     const int row0 = tm * BM, col0 = tn * BN;
+    if (!tile_has_rows(p.lens, p.t_pad, row0, BM, p.m)) return;
 
     // loaders: clamped (always legal) addresses + select, no branches around the loads; row bases hoisted
     const int mlast = p.m - 1, nlast = p.n - 1, klast = K - 4;
@@ -225,6 +242,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
     const int tid = threadIdx.x;
     const int arow = tid >> 3, akq = tid & 7, brow = tid >> 2, bsl = tid & 3;
     const int row0 = tm * BM, col0 = tn * BN;
+    if (!tile_has_rows(p.lens, p.t_pad, row0, BM, p.m)) return;
     const int mlast = p.m - 1, nlast = p.n - 1;
     const float* arow0[C::PA];
     const float* arow1[C::PA];
@@ -328,6 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
     const int tid = threadIdx.x;
     const int arow = tid >> 3, akq = tid & 7, qrow = tid >> 2, qsl = tid & 3;
     const int row0 = tm * BM, col0 = tn * BN;
+    if (!tile_has_rows(p.lens, p.t_pad, row0, BM, p.m)) return;
     const int mlast = p.m - 1, nlast = p.n - 1;
     size_t boff[C::QB];
 #pragma unroll
@@ -384,10 +403,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
 template <int NV>  // float4 per lane
 __global__ __launch_bounds__(256) void ln_gelu_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
                                                       int ldy, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int rows, int cols, float eps) {
+                                                      const float* __restrict__ beta, int rows, int cols, float eps,
+                                                      const int* __restrict__ lens, int t_pad) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (lens && (row % t_pad) >= lens[row / t_pad]) return;      // a row beyond its sequence's length: never read afterwards
     float4 v[NV];
     float sum = 0.f;
 #pragma unroll
@@ -490,6 +511,7 @@ bool launch_linear_x3_wide(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _
     if (force && force[0] == 'n') return false;
     if (p.n < 256 || (p.k0 + p.k1) % 32 != 0) return false;
     const long big = (long)cdiv(p.m, 256) * cdiv(p.n, 256);
+    if (!force && (long)cdiv(p.m, 128) * cdiv(p.n, 256) < 192) return false;      // too few wide tiles for 256 CUs: narrow tiles fill the chip better
     const bool use256 = force ? (force[1] == '2') : big >= 224;
     if (use256) launch_linear_x3w_t<4, 2, 4, APLANES>(p, a, wh, wl, inv, st);
     else launch_linear_x3w_t<2, 2, 4, APLANES>(p, a, wh, wl, inv, st);
@@ -537,7 +559,7 @@ extern "C" int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda
     return pram_launch_status("pram_linear_x3p_f32");
 }
 
-extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+static int linear_x3_impl(const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
                                   const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
                                   float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                   int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
@@ -550,7 +572,8 @@ extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float
         PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_x3_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
     if (m == 0) return PRAM_OK;
     LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
-              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE};
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE, lens, t_pad};
+    PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_x3_f32: lens needs t_pad > 0");
     int mi, wn;
     gemm::choose_tile(m, n, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
@@ -564,6 +587,25 @@ extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float
     if (wn == 2) { if (mi == 2) launch_linear_x3_t<2, 2>(p, wh, wl, inv, st); else launch_linear_x3_t<1, 2>(p, wh, wl, inv, st); }
     else         { if (mi == 2) launch_linear_x3_t<2, 1>(p, wh, wl, inv, st); else launch_linear_x3_t<1, 1>(p, wh, wl, inv, st); }
     return pram_launch_status("pram_linear_x3_f32");
+}
+
+extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+                                  const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
+                                  float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
+                                  int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
+    return linear_x3_impl(nullptr, 0, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
+                          m, n, alpha, flags, rot_cos, rot_sin, rot_cols, stream);
+}
+
+/* pram_linear_x3_f32 on a ragged token matrix: rows are sequences of t_pad rows, sequence s has lens[s] (device int32) valid
+   ones; output tiles that contain no valid row are skipped and left untouched (AdaGML: pruned / stopped pairs cost nothing). */
+extern "C" int pram_linear_x3_ragged_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+                                         const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
+                                         float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
+                                         int flags, const float* rot_cos, const float* rot_sin, int rot_cols, const int* lens,
+                                         int t_pad, void* stream) {
+    return linear_x3_impl(lens, t_pad, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
+                          m, n, alpha, flags, rot_cos, rot_sin, rot_cols, stream);
 }
 
 extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
@@ -610,7 +652,7 @@ extern "C" int pram_linear_f16_h16(const float* a0, int lda0, int k0, const floa
     return pram_launch_status("pram_linear_f16_h16");
 }
 
-extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+static int linear_f32_impl(const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
                                const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
                                float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
                                void* stream) {
@@ -623,8 +665,27 @@ extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a
     if (m == 0) return PRAM_OK;
     LinArgs p{a0, lda0, k0, a1, lda1, k1, w, bias, residual, ldr, out, ldo, m, n, alpha, flags,
               rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0};
+    PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_f32: lens needs t_pad > 0");
+    p.lens = lens;
+    p.t_pad = t_pad;
     launch_linear(p, 1, (hipStream_t)stream);
     return pram_launch_status("pram_linear_f32");
+}
+
+extern "C" int pram_linear_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                               const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                               float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                               void* stream) {
+    return linear_f32_impl(nullptr, 0, a0, lda0, k0, a1, lda1, k1, w, bias, residual, ldr, out, ldo, m, n, alpha, flags, rot_cos, rot_sin,
+                           rot_cols, stream);
+}
+
+extern "C" int pram_linear_ragged_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w,
+                                      const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                                      float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                                      const int* lens, int t_pad, void* stream) {
+    return linear_f32_impl(lens, t_pad, a0, lda0, k0, a1, lda1, k1, w, bias, residual, ldr, out, ldo, m, n, alpha, flags, rot_cos, rot_sin,
+                           rot_cols, stream);
 }
 
 extern "C" int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* b, int ldb,
@@ -639,18 +700,29 @@ extern "C" int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, co
     return pram_launch_status("pram_bgemm_nt_f32");
 }
 
-extern "C" int pram_layernorm_gelu_f32(const float* x, int ldx, float* y, int ldy, const float* gamma,
-                                       const float* beta, int rows, int cols, float eps, void* stream) {
-    PRAM_REQUIRE(x && y && gamma && beta, "pram_layernorm_gelu_f32: null pointer");
+static int layernorm_gelu_impl(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int rows, int cols,
+                               float eps, const int* lens, int t_pad, void* stream, const char* who) {
+    PRAM_REQUIRE(x && y && gamma && beta, "%s: null pointer", who);
     PRAM_REQUIRE(cols > 0 && cols <= 1024 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0,
-                 "pram_layernorm_gelu_f32: cols=%d must be <= 1024 and a multiple of 4", cols);
+                 "%s: cols=%d must be <= 1024 and a multiple of 4", who, cols);
+    PRAM_REQUIRE(!lens || t_pad > 0, "%s: lens needs t_pad > 0", who);
     if (rows == 0) return PRAM_OK;
     dim3 grid(cdiv(rows, 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (cols <= 256) hipLaunchKernelGGL(ln_gelu_kernel<1>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps);
-    else if (cols <= 512) hipLaunchKernelGGL(ln_gelu_kernel<2>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps);
-    else hipLaunchKernelGGL(ln_gelu_kernel<4>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps);
-    return pram_launch_status("pram_layernorm_gelu_f32");
+    if (cols <= 256) hipLaunchKernelGGL(ln_gelu_kernel<1>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps, lens, t_pad);
+    else if (cols <= 512) hipLaunchKernelGGL(ln_gelu_kernel<2>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps, lens, t_pad);
+    else hipLaunchKernelGGL(ln_gelu_kernel<4>, grid, blk, 0, st, x, ldx, y, ldy, gamma, beta, rows, cols, eps, lens, t_pad);
+    return pram_launch_status(who);
+}
+
+extern "C" int pram_layernorm_gelu_f32(const float* x, int ldx, float* y, int ldy, const float* gamma,
+                                       const float* beta, int rows, int cols, float eps, void* stream) {
+    return layernorm_gelu_impl(x, ldx, y, ldy, gamma, beta, rows, cols, eps, nullptr, 0, stream, "pram_layernorm_gelu_f32");
+}
+
+extern "C" int pram_layernorm_gelu_ragged_f32(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                              int rows, int cols, float eps, const int* lens, int t_pad, void* stream) {
+    return layernorm_gelu_impl(x, ldx, y, ldy, gamma, beta, rows, cols, eps, lens, t_pad, stream, "pram_layernorm_gelu_ragged_f32");
 }
 
 extern "C" int pram_fourier_encoding_f32(const float* kpts, const float* wr, float cx, float cy, float scale,

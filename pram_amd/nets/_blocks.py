@@ -87,11 +87,12 @@ def _cols(planes, lo: int, hi: int):
     return planes[0][:, lo:hi], planes[1][:, lo:hi]
 
 
-def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0"""
-    h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx)
-    ops.layernorm_gelu_(h, p["mlp.1.weight"], p["mlp.1.bias"])
-    return ops.linear(h, p["mlp.3.weight"], p["mlp.3.bias"], residual=x)
+def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor], lens=None, T: int = 0) -> torch.Tensor:
+    """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0.  lens / T: ragged sequences — tiles of
+    rows beyond every sequence's length are skipped (their rows are never read downstream)."""
+    h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx, lens=lens, t_pad=T)
+    ops.layernorm_gelu_(h, p["mlp.1.weight"], p["mlp.1.bias"], lens=lens, t_pad=T)
+    return ops.linear(h, p["mlp.3.weight"], p["mlp.3.bias"], residual=x, lens=lens, t_pad=T)
 
 
 def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, sin: torch.Tensor, S: int, T: int,
@@ -101,27 +102,28 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
     scale = DH ** -0.5
     if _split_path():
         # split-fp16 path: the projection writes q | k | v as (hi, lo) planes (plus fp32 when the column means need q / k)
-        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="also" if want_colmean else "only")
+        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="also" if want_colmean else "only",
+                             lens=lens, t_pad=T)
         q3, k3 = _cols(pl, 0, hid), _cols(pl, hid, 2 * hid)
         v3 = ops.value_planes_t(_cols(pl, 2 * hid, 3 * hid), S, HEADS, T, lens)
         if want_colmean:
             ctx, lse = ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens, want_lse=True)
             col = ops.attention_colmean(qkv[:, :hid], qkv[:, hid:2 * hid], lse, S, HEADS, T, T, scale, lens, lens)
-            return _mlp_tail(x, ctx, p), col
-        return _mlp_tail(x, ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens), p)
+            return _mlp_tail(x, ctx, p, lens, T), col
+        return _mlp_tail(x, ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens), p, lens, T)
     if _half_path() and not want_colmean:
         # fp16 path: the projection writes q | k | v as fp16 only (what the fp16 attention would round them to anyway)
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), half_copy="only")
         ctx = ops.attention_h16(h16[:, :hid], h16[:, hid:2 * hid], h16[:, 2 * hid:], S, HEADS, T, T, scale, lens, lens)
         return _mlp_tail(x, ctx, p)
-    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH))
+    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), lens=lens, t_pad=T)
     q, k, v = qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:]
     if want_colmean:
         ctx, lse = ops.attention(q, k, v, S, HEADS, T, T, scale, lens, lens, want_lse=True)
         col = ops.attention_colmean(q, k, lse, S, HEADS, T, T, scale, lens, lens)
-        return _mlp_tail(x, ctx, p), col
+        return _mlp_tail(x, ctx, p, lens, T), col
     ctx = ops.attention(q, k, v, S, HEADS, T, T, scale, lens, lens)
-    return _mlp_tail(x, ctx, p)
+    return _mlp_tail(x, ctx, p, lens, T)
 
 
 def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, lens: Optional[torch.Tensor],
@@ -131,29 +133,29 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     hid = HEADS * DH
     scale = DH ** -0.5     # (dh^-1/4)^2
     if _split_path():
-        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="also" if want_colmean else "only")
+        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="also" if want_colmean else "only", lens=lens, t_pad=T)
         qk3 = _cols(pl, 0, hid)
         v3 = ops.value_planes_t(_cols(pl, hid, 2 * hid), 2 * B, HEADS, T, lens)
         if want_colmean:
             ctx, lse = ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, want_lse=True, kv_shift=B)
             col = ops.attention_cross_colmean(qkv[:, :hid], lse, B, HEADS, T, scale, lens)
-            return _mlp_tail(x, ctx, p), col[:B], col[B:]
-        return _mlp_tail(x, ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B), p)
+            return _mlp_tail(x, ctx, p, lens, T), col[:B], col[B:]
+        return _mlp_tail(x, ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B), p, lens, T)
     if _half_path() and not want_colmean:
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], half_copy="only")
         qk16, v16 = h16[:, :hid], h16[:, hid:]
         ctx = ops.attention_h16(qk16, qk16, v16, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
         return _mlp_tail(x, ctx, p)
-    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"])          # [2B*T, 512] = [qk | v]
+    qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], lens=lens, t_pad=T)          # [2B*T, 512] = [qk | v]
     qk, v = qkv[:, :hid], qkv[:, hid:]
     # one launch for both directions: sequence s attends to sequence (s + B) mod 2B
     if want_colmean:
         ctx, lse = ops.attention_cross(qk, v, B, HEADS, T, scale, lens, want_lse=True)
         col = ops.attention_cross_colmean(qk, lse, B, HEADS, T, scale, lens)
         # rows 0..B-1: attn10 column means -> per set-0 token ; rows B..2B-1: attn01 column means -> per set-1 token
-        return _mlp_tail(x, ctx, p), col[:B], col[B:]
+        return _mlp_tail(x, ctx, p, lens, T), col[:B], col[B:]
     ctx = ops.attention_cross(qk, v, B, HEADS, T, scale, lens)
-    return _mlp_tail(x, ctx, p)
+    return _mlp_tail(x, ctx, p, lens, T)
 
 
 def with_model_precision(fn):

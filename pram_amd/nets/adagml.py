@@ -115,15 +115,16 @@ class AdaGML(GML):
     def stop_iteration(self, m_last, n_last, m_current, n_current, confidence=0.975):
         return (m_current + n_current) / (m_last + n_last) > confidence
 
-    def _pool_logit(self, pp, x, score4):
-        """PoolingLayer.forward up to the pre-sigmoid logit (nets/adagml.py:132-136)."""
-        s = ops.linear(score4, pp["se0_w"], pp["se0_b"])
-        ops.layernorm_gelu_(s, pp["se1_w"], pp["se1_b"])
-        s = ops.linear(s, pp["se3_w"], pp["se3_b"])
-        xx = ops.linear(x, pp["proj_w"], pp["proj_b"])
-        h = ops.linear(xx, pp["pr0_w"], pp["pr0_b"], x2=s)
-        ops.layernorm_gelu_(h, pp["pr1_w"], pp["pr1_b"])
-        return ops.linear(h, pp["pr3_w"], pp["pr3_b"])[:, 0].contiguous()
+    def _pool_logit(self, pp, x, score4, lens=None, T: int = 0):
+        """PoolingLayer.forward up to the pre-sigmoid logit (nets/adagml.py:132-136); rows beyond lens are skipped."""
+        kw = dict(lens=lens, t_pad=T)
+        s = ops.linear(score4, pp["se0_w"], pp["se0_b"], **kw)
+        ops.layernorm_gelu_(s, pp["se1_w"], pp["se1_b"], **kw)
+        s = ops.linear(s, pp["se3_w"], pp["se3_b"], **kw)
+        xx = ops.linear(x, pp["proj_w"], pp["proj_b"], **kw)
+        h = ops.linear(xx, pp["pr0_w"], pp["pr0_b"], x2=s, **kw)
+        ops.layernorm_gelu_(h, pp["pr1_w"], pp["pr1_b"], **kw)
+        return ops.linear(h, pp["pr3_w"], pp["pr3_b"], **kw)[:, 0].contiguous()
 
     @torch.no_grad()
     @blk.with_model_precision
@@ -175,7 +176,7 @@ class AdaGML(GML):
             score4 = torch.zeros(2 * B, T, 4, device=dev, dtype=torch.float32)
             score4[:, :, 0] = col_self
             score4[:B, :, 1], score4[B:, :, 1] = col0, col1
-            logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * B * T, 4)).view(2 * B, T)
+            logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * B * T, 4), lens_eff, T).view(2 * B, T)
             stop_now = torch.zeros_like(active)
             if ni >= 1:
                 thr = self.confidence_threshold(ni)
@@ -194,9 +195,11 @@ class AdaGML(GML):
             if ni == nI - 1:
                 stop_now = active.clone()                  # loop exhausted: use the last layer (adagml.py:374); also n_layers == 1
             if ni >= 1 or ni == nI - 1:
-                md = ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25).view(2 * B, T, d)
+                # out_proj only for the pairs that stop at this layer, written straight into their rows of md_final: the ragged
+                # GEMM skips every tile of the other pairs (lens 0) and leaves their rows as they are
                 sel = stop_now.repeat(2)
-                md_final = torch.where(sel[:, None, None], md, md_final)
+                lens_stop = torch.where(sel, lens, torch.zeros_like(lens)).contiguous()
+                ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25, out=md_final.view(2 * B * T, d), lens=lens_stop, t_pad=T)
                 lens_final = torch.where(sel, lens, lens_final)
                 ind_final = torch.where(sel[:, None], ind, ind_final)
                 stop_layer = torch.where(stop_now, torch.full_like(stop_layer, ni), stop_layer)

@@ -38,7 +38,7 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
            rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, half_copy: str = "no", split_out: str = "no",
-           precision: Optional[str] = None):
+           precision: Optional[str] = None, lens: Optional[torch.Tensor] = None, t_pad: int = 0):
     """out = alpha * ([x | x2] @ w.T + bias) + residual.  x [..., k0] (contiguous rows), w [n, k0+k1].
     precision: None = ops.gemm_precision; "f32" exact-fp32 MFMA, "x3" split-fp16 (three fp16 MFMAs per product, fp32-class
     accuracy), "f16" single fp16 product (BASELINE C5).  Shapes a fast path cannot take (K not a multiple of 32 / 64)
@@ -46,10 +46,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     half_copy (f16 path only): "also" -> returns (out fp32, out fp16), "only" -> returns (None, out fp16): the fp16 operand
     of attention_h16.
     split_out (x3 path only): "also" -> (out fp32, (hi, lo)), "only" -> (None, (hi, lo)): the result * 16 as two fp16 planes,
-    the operand format of attention_x3."""
+    the operand format of attention_x3.
+    lens / t_pad (f32 and x3 paths): ragged token matrix — rows are sequences of t_pad rows with lens[s] valid ones; output tiles
+    without a valid row are skipped and left untouched."""
     L = _lib.load()
     x = x.contiguous()
     m, k0 = _rows2d(x, "x")
+    if lens is not None:
+        assert t_pad > 0 and m % t_pad == 0 and lens.dtype == torch.int32 and lens.numel() == m // t_pad
     k1 = 0
     if x2 is not None:
         x2 = x2.contiguous()
@@ -89,25 +93,25 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         o32 = out if split_out == "also" else None
         if m:
             wh, wl, ws = split_weight(w)
-            _lib.check(L.pram_linear_x3_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n,
-                                            _p(o32), n, _p(planes[0]), _p(planes[1]), n, m, n, float(alpha), flags, _p(rc), _p(rs),
-                                            int(rcols), _st()), "pram_linear_x3_f32")
+            _lib.check(L.pram_linear_x3_ragged_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n,
+                                                   _p(o32), n, _p(planes[0]), _p(planes[1]), n, m, n, float(alpha), flags, _p(rc), _p(rs),
+                                                   int(rcols), _p(lens), int(t_pad), _st()), "pram_linear_x3_f32")
         return o32, (planes[0], planes[1])
     if m == 0:          # empty token set: nothing to launch (an empty tensor has a null data pointer)
         return out
     if usex3:
         wh, wl, ws = split_weight(w)
-        _lib.check(L.pram_linear_x3_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n, _p(out), n,
-                                        None, None, 0, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
-                   "pram_linear_x3_f32")
+        _lib.check(L.pram_linear_x3_ragged_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(bias), _p(residual), n, _p(out), n,
+                                               None, None, 0, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _p(lens), int(t_pad),
+                                               _st()), "pram_linear_x3_f32")
         return out
     if use16:
         _lib.check(L.pram_linear_f16_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual),
                                          n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
                    "pram_linear_f16_f32")
         return out
-    _lib.check(L.pram_linear_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(w), _p(bias), _p(residual),
-                                 n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+    _lib.check(L.pram_linear_ragged_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(w), _p(bias), _p(residual),
+                                        n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _p(lens), int(t_pad), _st()),
                "pram_linear_f32")
     return out
 
@@ -160,12 +164,13 @@ def bgemm_nt(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, ldc: Optional
     return c
 
 
-def layernorm_gelu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def layernorm_gelu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                    lens: Optional[torch.Tensor] = None, t_pad: int = 0) -> torch.Tensor:
     L = _lib.load()
     rows, cols = _rows2d(x, "x")
     assert x.is_contiguous()
-    _lib.check(L.pram_layernorm_gelu_f32(_p(x), cols, _p(x), cols, _p(gamma), _p(beta), rows, cols, float(eps), _st()),
-               "pram_layernorm_gelu_f32")
+    _lib.check(L.pram_layernorm_gelu_ragged_f32(_p(x), cols, _p(x), cols, _p(gamma), _p(beta), rows, cols, float(eps), _p(lens), int(t_pad),
+                                                _st()), "pram_layernorm_gelu_f32")
     return x
 
 

@@ -173,3 +173,28 @@ def test_graphed_pipelines_own_their_scratch(dev):
         assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
     with pytest.raises(ValueError):
         GraphedPipeline(pipe, a, None, stages="er").run(a, ra)
+
+
+@pytest.mark.parametrize("prec", ["x3", "f32"])
+def test_ragged_linear_touches_only_valid_rows(dev, prec):
+    """lens / t_pad: valid rows equal the plain call bit for bit, rows beyond their sequence's length keep what `out` held
+    (AdaGML commits out_proj of the pairs that stop at a layer into a persistent buffer), whole tiles of dead rows are skipped."""
+    from pram_amd import ops
+    T, S, K, N = 300, 5, 256, 256
+    x = W.normal(41, "rag/x", (S * T, K)).to(dev)
+    w = W.normal(41, "rag/w", (N, K), 1.0 / 16).to(dev)
+    b = W.normal(41, "rag/b", (N,), 0.1).to(dev)
+    lens = torch.tensor([300, 0, 17, 129, 0], dtype=torch.int32, device=dev)
+    full = ops.linear(x, w, b, precision=prec)
+    out = torch.full((S * T, N), -7.0, device=dev)
+    ops.linear(x, w, b, precision=prec, out=out, lens=lens, t_pad=T)
+    o3, f3 = out.view(S, T, N), full.view(S, T, N)
+    for s_, n in enumerate(lens.tolist()):
+        assert torch.equal(o3[s_, :n], f3[s_, :n])
+        assert bool((o3[s_, n:] == -7.0).all())
+    h = ops.linear(x, w, b, precision=prec).clone()
+    g, bt = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    ref = ops.layernorm_gelu_(h.clone(), g, bt)
+    got = ops.layernorm_gelu_(h.clone(), g, bt, lens=lens, t_pad=T).view(S, T, N)
+    for s_, n in enumerate(lens.tolist()):
+        assert torch.equal(got[s_, :n], ref.view(S, T, N)[s_, :n]) and torch.equal(got[s_, n:], h.view(S, T, N)[s_, n:])

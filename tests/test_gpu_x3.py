@@ -141,7 +141,8 @@ def test_attention_x3_vs_fp64(dev, B, M, N, ragged):
     # S = K Q^T is a full three-term split product (the log-sum-exp agrees with the f32-MFMA kernel to 1e-5); the probabilities
     # enter P V as one fp16 each, normalised by the sum of the same rounded values: a 2^-12 relative perturbation of the softmax
     # weights, independent per key -> errors of a few 1e-5 on O(1) values (vs 1e-6 for the exact kernels, 1e-3 for the fp16 path)
-    assert ex3 < 1e-4 and el < 1e-5
+    # below 1024 keys the kernel splits P as well (three MFMAs per product): fp32-class like the GEMMs
+    assert (ex3 < 1e-4 and el < 1e-4) if N >= 1024 else (ex3 < 3e-6 and el < 1e-5)
 
 
 def test_attention_x3_cross_equals_two_directions(dev):
@@ -175,7 +176,7 @@ def test_attention_x3_spike_and_empty(dev):
     ref = _attn_ref(sp(q, M), sp(k, N), sp(v, N), 0.125).permute(0, 2, 1, 3).reshape(M, 256)
     vt = ops.value_planes_t(_planes(ops, v.to(dev)), B, 4, N)
     out = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), vt, B, 4, M, N, 0.125)
-    assert err(out, ref) < 1e-4
+    assert err(out, ref) < 1e-4          # 1024 keys: probabilities as one fp16
     kl = torch.zeros(1, dtype=torch.int32, device=dev)
     out0 = ops.attention_x3(_planes(ops, q.to(dev)), _planes(ops, k.to(dev)), vt, B, 4, M, N, 0.125, None, kl)
     assert float(out0.abs().max()) == 0.0
