@@ -318,7 +318,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
     auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + qrow + C::RQ * pp) < p.cout; };
     f32x16 acc[MI][2];
-    mainloop<MI, WM, WN, false>(smem, adv, la, oka, lb, okb, p.k / BK, gemmx3::ACT_SCALE, acc);
+    auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
+    auto bptr = [&](int row, int plane, int kt) -> const _Float16* {
+        return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * p.k + kt * BK;
+    };
+    mainloop<MI, WM, WN, false, 0, 1>(smem, adv, la, oka, lb, okb, aptr, bptr, p.k / BK, gemmx3::ACT_SCALE, acc);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -45,12 +45,41 @@ struct alignas(16) Smem {
     _Float16 bl[2][C::BN * BK];
 };  // <4,2,4>: 128 KiB; <2,2,4>: 96 KiB
 
+// LDS-DMA staging of a pre-split operand tile (rows x 32 halves per plane): one global_load_lds_dwordx4 moves 64 x 16 B from
+// per-lane global addresses to 1 KiB of LDS at (wave-uniform base) + 16 * lane, i.e. 16 consecutive 64-B tile rows.  The LDS
+// image is the swizzled one the fragment reads expect, so the swizzle is applied on the SOURCE side: lane (row_local = l / 4,
+// physical slot = l % 4) fetches logical slot (l % 4) ^ ((row >> 2) & 3).  No VGPR staging, no ds_write, no VALU.
+//   rowptr(row, plane) -> const _Float16* of tile row `row` (clamped to a legal row by the caller) at the chunk's k offset
+template <int ROWS, int NWAVES, class RowPtr>
+__device__ __forceinline__ void dma_tile(_Float16* lds_hi, _Float16* lds_lo, RowPtr& rowptr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PIECES = ROWS / 16;                 // 1-KiB pieces per plane
+#pragma unroll
+    for (int i = 0; i < (2 * PIECES + NWAVES - 1) / NWAVES; ++i) {
+        const int piece = wave + NWAVES * i;          // wave-uniform
+        if (piece < 2 * PIECES) {
+            const int plane = piece / PIECES, pc = piece % PIECES;
+            const int row = pc * 16 + (lane >> 2);
+            const int slot = (lane & 3) ^ ((row >> 2) & 3);
+            const _Float16* src = rowptr(row, plane) + slot * 8;
+            _Float16* dst = (plane ? lds_lo : lds_hi) + pc * 16 * BK;      // wave-uniform
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+        }
+    }
+}
+
 // APLANES = false: ALoad(p, kt) -> raw float4 A[row = tid/8 + RA p][kt*32 + (tid%8)*4 ..+3] (fp32, split here)
 // APLANES = true : ALoad(p, kt, plane) -> raw uint4 plane[row = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7]
 // BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7];  *Ok: predicates;  Adv as gemm_core_x3.h
-template <int MI, int WM, int WN, bool APLANES, class Adv, class ALoad, class AOk, class BLoad, class BOk>
-__device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
-                                         float a_scale, f32x16 (&acc)[MI][2]) {
+// ABL (profiling only, PRAM_GEMM_ABLATE): bit 0 = no staging after the first chunk (LDS content stale), bit 1 = fragments read
+// once per chunk instead of per k-step.  Results are garbage; the remaining work keeps its shape.
+// DMA: 0 = register staging for both operands; 1 = B (weights) by LDS-DMA (bptr(row, plane, kt) -> row pointer at the chunk's k);
+//      2 = A planes by LDS-DMA as well (aptr likewise; APLANES only).  Rows are clamped by the pointer functors; an out-of-range
+//      row is a duplicate whose outputs the epilogue never stores.
+template <int MI, int WM, int WN, bool APLANES, int ABL, int DMA, class Adv, class ALoad, class AOk, class BLoad, class BOk, class APtr, class BPtr>
+__device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, APtr& aptr, BPtr& bptr,
+                                         int nk, float a_scale, f32x16 (&acc)[MI][2]) {
+    static_assert(DMA < 2 || APLANES, "A can only travel by DMA when it is already split");
     using C = Cfg<MI, WM, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -67,35 +96,55 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     constexpr int NA = APLANES ? C::QA : C::PA;
-    float4 ra[APLANES ? 1 : C::PA];
-    uint4 rah[APLANES ? C::QA : 1], ral[APLANES ? C::QA : 1];
-    uint4 rbh[C::QB], rbl[C::QB];
-    unsigned ok = 0u;
-    auto issue = [&](int kt) {
-        ok = 0u;
-#pragma unroll
-        for (int p = 0; p < NA; ++p) {
-            if constexpr (APLANES) { rah[p] = la(p, kt, 0); ral[p] = la(p, kt, 1); }
-            else ra[p] = la(p, kt);
-            ok |= (oka(p, kt) ? 1u : 0u) << p;
-        }
-#pragma unroll
-        for (int p = 0; p < C::QB; ++p) { rbh[p] = lb(p, kt, 0); rbl[p] = lb(p, kt, 1); ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+    struct Regs {
+        float4 a[APLANES ? 1 : C::PA];
+        uint4 ah[APLANES ? C::QA : 1], al[APLANES ? C::QA : 1];
+        uint4 bh[C::QB], bl[C::QB];
+        unsigned ok;
     };
-    auto commit = [&](int buf) {
+    auto issue = [&](int kt, Regs& g) {
+        g.ok = 0u;
+        if constexpr (DMA < 2) {
 #pragma unroll
-        for (int p = 0; p < NA; ++p) {
+            for (int p = 0; p < NA; ++p) {
+                if constexpr (APLANES) { g.ah[p] = la(p, kt, 0); g.al[p] = la(p, kt, 1); }
+                else g.a[p] = la(p, kt);
+                g.ok |= (oka(p, kt) ? 1u : 0u) << p;
+            }
+        }
+        if constexpr (DMA < 1) {
+#pragma unroll
+            for (int p = 0; p < C::QB; ++p) { g.bh[p] = lb(p, kt, 0); g.bl[p] = lb(p, kt, 1); g.ok |= (okb(p, kt) ? 1u : 0u) << (8 + p); }
+        }
+    };
+    // the DMA part of a chunk's staging: issued with the register loads, lands in LDS buffer `buf` on its own
+    auto dma = [&](int buf, int kt) {
+        if constexpr (DMA >= 1) {
+            auto bp = [&](int row, int plane) { return bptr(row, plane, kt); };
+            dma_tile<C::BN, C::NT / 64>(s.bh[buf], s.bl[buf], bp);
+        }
+        if constexpr (DMA >= 2) {
+            auto ap = [&](int row, int plane) { return aptr(row, plane, kt); };
+            dma_tile<C::BM, C::NT / 64>(s.ah[buf], s.al[buf], ap);
+        }
+    };
+    auto dma_wait = [&]() {
+        if constexpr (DMA >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto commit = [&](int buf, const Regs& g) {
+#pragma unroll
+        for (int p = 0; p < (DMA < 2 ? NA : 0); ++p) {
             if constexpr (APLANES) {
                 const int row = qrow + C::RQ * p;
-                uint4 vh = rah[p], vl = ral[p];
-                if (!((ok >> p) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+                uint4 vh = g.ah[p], vl = g.al[p];
+                if (!((g.ok >> p) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
                 const int off = row * BK + swz(qsl, row) * 8;
                 *reinterpret_cast<uint4*>(&s.ah[buf][off]) = vh;
                 *reinterpret_cast<uint4*>(&s.al[buf][off]) = vl;
             } else {
                 const int row = arow + C::RA * p;
-                float4 v = ra[p];
-                if (!((ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = g.a[p];
+                if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 half4 hi, lo;
                 split4(v, a_scale, hi, lo);
                 const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;
@@ -104,10 +153,10 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
             }
         }
 #pragma unroll
-        for (int p = 0; p < C::QB; ++p) {
+        for (int p = 0; p < (DMA < 1 ? C::QB : 0); ++p) {
             const int row = qrow + C::RQ * p;
-            uint4 vh = rbh[p], vl = rbl[p];
-            if (!((ok >> (8 + p)) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+            uint4 vh = g.bh[p], vl = g.bl[p];
+            if (!((g.ok >> (8 + p)) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
             const int off = row * BK + swz(qsl, row) * 8;
             *reinterpret_cast<uint4*>(&s.bh[buf][off]) = vh;
             *reinterpret_cast<uint4*>(&s.bl[buf][off]) = vl;
@@ -142,19 +191,51 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
         }
     };
 
-    adv(0);
-    issue(0);
-    commit(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) { adv(kt + 1); issue(kt + 1); }
-        __builtin_amdgcn_sched_barrier(0);       // the loads go out first; nothing of commit() (its waits) moves above the MFMAs
-        kstep(kt & 1, 0);
-        kstep(kt & 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) commit((kt + 1) & 1);
+    if constexpr (MI <= 2) {
+        // 128-row tiles have the registers for two chunks of loads in flight (chunk kt + 2 requested before chunk kt is
+        // multiplied): with one workgroup per CU all eight waves otherwise wait on the same load round trip at the same time
+        Regs g0, g1;
+        adv(0);
+        issue(0, g0);
+        dma(0, 0);
+        if (nk > 1) { adv(1); issue(1, g1); }
+        commit(0, g0);
+        dma_wait();
         __syncthreads();
+        auto step = [&](int kt, Regs& fresh, Regs& next) {
+            if (kt + 1 < nk && !(ABL & 1)) dma((kt + 1) & 1, kt + 1);      // the other LDS buffer is free since the last barrier
+            if (kt + 2 < nk && !(ABL & 1)) { adv(kt + 2); issue(kt + 2, fresh); }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(kt & 1, 0);
+            kstep(kt & 1, (ABL & 2) ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk && !(ABL & 1)) commit((kt + 1) & 1, next);
+            dma_wait();
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, g0, g1);
+            if (kt + 1 < nk) step(kt + 1, g1, g0);
+        }
+    } else {
+        Regs g;
+        adv(0);
+        issue(0, g);
+        dma(0, 0);
+        commit(0, g);
+        dma_wait();
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more && !(ABL & 1)) { adv(kt + 1); issue(kt + 1, g); dma((kt + 1) & 1, kt + 1); }
+            __builtin_amdgcn_sched_barrier(0);       // the loads go out first; nothing of commit() (its waits) moves above the MFMAs
+            kstep(kt & 1, 0);
+            kstep(kt & 1, (ABL & 2) ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && !(ABL & 1)) commit((kt + 1) & 1, g);
+            dma_wait();
+            __syncthreads();
+        }
     }
 }
 

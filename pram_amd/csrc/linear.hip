@@ -331,7 +331,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3p_kernel(LinArgs p, Pl
 
 // Wide-tile split-fp16 GEMM (gemm_core_x3w.h): 256 x 256 or 128 x 256 outputs per 512-thread workgroup, A as fp32 (split while
 // staged) or as pre-split planes.  Same arithmetic and accumulation order as linear_x3_kernel: bit-identical results.
-template <int MI, int WM, int WN, bool APLANES>
+template <int MI, int WM, int WN, bool APLANES, int ABL = 0, int DMA = 1>
 __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, PlaneArgs a, const _Float16* __restrict__ wh,
                                                                       const _Float16* __restrict__ wl, float inv) {
     using namespace gemmx3w;
@@ -354,6 +354,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
     auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + qrow + C::RQ * pp) < p.n; };
     auto adv = [](int) {};
+    auto bptr = [&](int row, int plane, int kt) -> const _Float16* {
+        return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * K + kt * BK;
+    };
     f32x16 acc[MI][2];
     if constexpr (APLANES) {
         size_t aoff0[C::QA], aoff1[C::QA];
@@ -370,7 +373,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             return *reinterpret_cast<const uint4*>((plane ? a.a0l : a.a0h) + aoff0[pp] + k);
         };
         auto oka = [&](int pp, int kt) -> bool { return (row0 + qrow + C::RQ * pp) < p.m; };
-        mainloop<MI, WM, WN, true>(smem, adv, la, oka, lb, okb, K / BK, gemmx3::ACT_SCALE, acc);
+        auto aptr = [&](int row, int plane, int kt) -> const _Float16* {
+            const size_t rc = (size_t)min(row0 + row, mlast);
+            const int k = kt * BK;
+            if (k >= p.k0 && p.k1 > 0) return (plane ? a.a1l : a.a1h) + rc * a.lda1 + (k - p.k0);
+            return (plane ? a.a0l : a.a0h) + rc * a.lda0 + k;
+        };
+        mainloop<MI, WM, WN, true, ABL, (DMA ? 2 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc);
     } else {
         const float* arow0[C::PA];
         const float* arow1[C::PA];
@@ -386,7 +395,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
         };
         auto oka = [&](int pp, int kt) -> bool { return (row0 + arow + C::RA * pp) < p.m; };
-        mainloop<MI, WM, WN, false>(smem, adv, la, oka, lb, okb, K / BK, gemmx3::ACT_SCALE, acc);
+        auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
+        mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc);
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -500,7 +510,17 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
         (void)hipFuncSetAttribute((const void*)linear_x3w_kernel<MI, WM, WN, APLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv);
+    static const char* abl = getenv("PRAM_GEMM_ABLATE");
+    const int ab = abl ? atoi(abl) : 0;
+    if (ab == 0) { hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv); return; }
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv);
+    };
+    if (ab == 8) go(linear_x3w_kernel<MI, WM, WN, APLANES, 0, 0>);       // register staging for both operands (no LDS-DMA)
+    else if (ab == 1) go(linear_x3w_kernel<MI, WM, WN, APLANES, 1>);
+    else if (ab == 2) go(linear_x3w_kernel<MI, WM, WN, APLANES, 2>);
+    else go(linear_x3w_kernel<MI, WM, WN, APLANES, 3>);
 }
 
 // wide tiles (gemm_core_x3w.h) for outputs at least 256 columns wide: 256 x 256 when that still gives every CU a workgroup,
