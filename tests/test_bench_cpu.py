@@ -37,3 +37,14 @@ def test_committed_bench_line_is_well_formed():
     assert abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.05          # no over-fetch
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_committed_round2_bench_line_is_well_formed():
+    line = json.loads((ROOT / "profiles" / "r02_bench_default.json").read_text())
+    assert line["unit"] == "queries/s" and line["n_gpus"] == 1 and line["vs_baseline"] is None and line["scaling"] == "weak"
+    assert line["config"]["precision"] == "x3" and line["dtype"].startswith("f32 results")
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and abs(rf["peak"] - 2500.0 / 3) < 0.1
+    assert line["parity"]["ok"] and line["parity"]["match"]["indices_identical"] and line["config"]["matches_last_step"] > 0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and set(cb["stage_seconds"]) == {"extract", "recognise", "match"}
