@@ -344,68 +344,97 @@ struct GConvArgs {
 };
 
 __global__ __launch_bounds__(256) void gconv3x3_kernel(GConvArgs p) {
+    // Two FMAs per instruction (v_pk_fma_f32) with both operands naturally paired: adjacent INPUT channels (ci, ci + 1) are
+    // adjacent in the NHWC pixel and in the [co][tap][ci] weight row, so every output accumulates an even-ci and an odd-ci
+    // partial sum in one 64-bit register pair (added at the end) and nothing has to be broadcast or shuffled.
+    //
+    // The (4 + 2) x (64 + 2) pixel window of the workgroup's 32 channels is staged through LDS once: read from global memory
+    // with 8 lanes per pixel (128 contiguous bytes), where the direct form had every lane fetch its own 32 bytes out of a
+    // different cache line for each of the 9 taps (64 lines per load instruction: the kernel was bound by L1 requests, 545 us
+    // against 72 us of FMA issue and 105 us of HBM time).  Pixel stride 36 floats: the 16 lanes of a ds_read_b128 group land
+    // on 16 distinct bank quads.
+    constexpr int PXS = 36, TW = 66, TH = 6;
     __shared__ __attribute__((aligned(16))) float sw[4][8 * 72];
+    __shared__ __attribute__((aligned(16))) float sx[TH * TW * PXS];
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y * 4 + wave;
     for (int i = lane; i < 576; i += 64) sw[wave][i] = p.w[(size_t)g * 576 + i];
-    __syncthreads();
     int t = blockIdx.x;
     const int xt = t % p.xtiles; t /= p.xtiles;
     const int yt = t % p.ytiles;
     const int b = t / p.ytiles;
-    const int x = xt * 64 + lane;
-    const int y0 = yt * 4;
-    const bool xok = x < p.wd;
-    const float* ib = p.in + (size_t)b * p.h * p.wd * p.c + g * 8;
+    const int x0 = xt * 64, y0 = yt * 4;
+    {
+        // all 13 loads of a thread are issued before the first one is consumed (one round trip, not thirteen)
+        const float* ibq = p.in + (size_t)b * p.h * p.wd * p.c + blockIdx.y * 32;
+        constexpr int NLD = (TH * TW * 8 + 255) / 256;
+        float4 v[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int q = i & 7, pix = min(i >> 3, TH * TW - 1);
+            const int ty = pix / TW, tx = pix - ty * TW;
+            const int iy = min(max(y0 + ty - 1, 0), p.h - 1), ix = min(max(x0 + tx - 1, 0), p.wd - 1);
+            v[j] = *reinterpret_cast<const float4*>(ibq + ((size_t)iy * p.wd + ix) * p.c + q * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int q = i & 7, pix = i >> 3;
+            const int ty = pix / TW, tx = pix - ty * TW;
+            const int iy = y0 + ty - 1, ix = x0 + tx - 1;
+            if (pix < TH * TW) {
+                const bool in = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+                *reinterpret_cast<float4*>(&sx[pix * PXS + q * 4]) = in ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    f2 acc2[4][8];
+#pragma unroll
+    for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc2[ro][o] = (f2){0.f, 0.f};
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {   // one tap's 64 weights live at a time (full unroll spills)
+        const int ky = tap / 3, kx = tap - ky * 3;
+        f2 wt[8][4];                       // [co][pair of ci]
+        const float* ws = &sw[wave][tap * 8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float4 w0 = *reinterpret_cast<const float4*>(ws + o * 72);
+            const float4 w1 = *reinterpret_cast<const float4*>(ws + o * 72 + 4);
+            wt[o][0] = (f2){w0.x, w0.y}; wt[o][1] = (f2){w0.z, w0.w};
+            wt[o][2] = (f2){w1.x, w1.y}; wt[o][3] = (f2){w1.z, w1.w};
+        }
+#pragma unroll
+        for (int ro = 0; ro < 4; ++ro) {
+            const float* src = &sx[((ro + ky) * TW + lane + kx) * PXS + wave * 8];      // zero padding is in the tile
+            const float4 a0 = *reinterpret_cast<const float4*>(src);
+            const float4 a1 = *reinterpret_cast<const float4*>(src + 4);
+            const f2 xp[4] = {(f2){a0.x, a0.y}, (f2){a0.z, a0.w}, (f2){a1.x, a1.y}, (f2){a1.z, a1.w}};
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+#pragma unroll
+                for (int ip = 0; ip < 4; ++ip) acc2[ro][o] = __builtin_elementwise_fma(xp[ip], wt[o][ip], acc2[ro][o]);
+        }
+    }
     float acc[4][8];
 #pragma unroll
     for (int ro = 0; ro < 4; ++ro)
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[ro][o] = 0.f;
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {   // one tap's 64 weights live at a time (full unroll spills)
-        const int ky = tap / 3, kx = tap - ky * 3;
-        {
-            float wt[8][8];
-            const float* ws = &sw[wave][tap * 8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const float4 w0 = *reinterpret_cast<const float4*>(ws + o * 72);
-                const float4 w1 = *reinterpret_cast<const float4*>(ws + o * 72 + 4);
-                wt[o][0] = w0.x; wt[o][1] = w0.y; wt[o][2] = w0.z; wt[o][3] = w0.w;
-                wt[o][4] = w1.x; wt[o][5] = w1.y; wt[o][6] = w1.z; wt[o][7] = w1.w;
-            }
-            const int ix = x + kx - 1;
-            const bool cx_ok = xok && (unsigned)ix < (unsigned)p.wd;
-            const int ixc = min(max(ix, 0), p.wd - 1);
-#pragma unroll
-            for (int ro = 0; ro < 4; ++ro) {
-                const int iy = y0 + ro + ky - 1;
-                const bool ok = cx_ok && (unsigned)iy < (unsigned)p.h;
-                const int iyc = min(max(iy, 0), p.h - 1);
-                const float* src = ib + ((size_t)iyc * p.wd + ixc) * p.c;
-                float4 a0 = *reinterpret_cast<const float4*>(src);
-                float4 a1 = *reinterpret_cast<const float4*>(src + 4);
-                if (!ok) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
-                const float xin[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-                for (int o = 0; o < 8; ++o)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[ro][o] = fmaf(xin[i], wt[o][i], acc[ro][o]);
-            }
-        }
-    }
-    if (!xok) return;
+        for (int o = 0; o < 8; ++o) acc[ro][o] = acc2[ro][o][0] + acc2[ro][o][1];
     float sc[8], sh[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         sc[o] = p.scale ? p.scale[g * 8 + o] : 1.f;
         sh[o] = p.scale ? p.shift[g * 8 + o] : 0.f;
     }
+    // results go back through the (now free) LDS tile so that the stores are 128 contiguous bytes per pixel as well
+    __syncthreads();
 #pragma unroll
     for (int ro = 0; ro < 4; ++ro) {
-        const int y = y0 + ro;
-        if (y >= p.h) break;
         float res[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -414,9 +443,19 @@ __global__ __launch_bounds__(256) void gconv3x3_kernel(GConvArgs p) {
             if (p.relu) v = fmaxf(v, 0.f);
             res[o] = v;
         }
-        float* dst = p.out + (((size_t)b * p.h + y) * p.wd + x) * p.c + g * 8;
+        float* dst = &sx[(ro * 64 + lane) * PXS + wave * 8];
         *reinterpret_cast<float4*>(dst) = make_float4(res[0], res[1], res[2], res[3]);
         *reinterpret_cast<float4*>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+    }
+    __syncthreads();
+    float* ob = p.out + (size_t)b * p.h * p.wd * p.c + blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j;
+        const int q = i & 7, pix = i >> 3;          // pix = ro * 64 + px
+        const int y = y0 + (pix >> 6), xx = x0 + (pix & 63);
+        if (y < p.h && xx < p.wd)
+            *reinterpret_cast<float4*>(ob + ((size_t)y * p.wd + xx) * p.c + q * 4) = *reinterpret_cast<const float4*>(&sx[pix * PXS + q * 4]);
     }
 }
 

@@ -122,18 +122,29 @@ __global__ __launch_bounds__(256) void sink_iter_kernel(const int* __restrict__ 
 #pragma unroll
     for (int t = 0; t < NV; ++t) cacc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Pb = w.P + (size_t)b * (m_max + 1) * ldw;
+    // the next row of the wave is requested before the current one is reduced: a row is one dependent chain (load -> dot ->
+    // wave reduction -> u_i -> column accumulation), and without the prefetch every row pays a full memory round trip
+    float4 nx[NV];
+    auto rload = [&](int i, float4 (&dst)[NV]) {
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int c = (t * 64 + lane) * 4;
+            dst[t] = (c < ldw && i < rend) ? *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    rload(rbeg + wave, nx);
     for (int i = rbeg + wave; i < rend; i += 4) {
         float4 pr[NV];
         float dot = 0.f;
 #pragma unroll
+        for (int t = 0; t < NV; ++t) pr[t] = nx[t];
+        rload(i + 4, nx);
+#pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int c = (t * 64 + lane) * 4;
             if (c < ldw) {
-                pr[t] = *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c);
                 const float4 vv = *reinterpret_cast<const float4*>(sv + c);
                 dot += (pr[t].x * vv.x + pr[t].y * vv.y) + (pr[t].z * vv.z + pr[t].w * vv.w);
-            } else {
-                pr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         dot = wave_sum(dot);
