@@ -85,6 +85,13 @@ int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int l
                        int ldo16, int m, int n, float alpha, int flags, const float* rot_cos,
                        const float* rot_sin, int rot_cols, void* stream);
 
+/* Profiling aid (no product caller): with PRAM_GEMM_ABLATE=4 in the environment the wide split-fp16 GEMM adds, per workgroup,
+ * the shader-clock cycles of each main-loop phase to eight device counters: [0] issue + MFMA k-steps, [1] wait for the
+ * chunk's loads, [2] commit (split + LDS writes), [3] barrier, [4] whole main loop, [5] workgroups, [6] epilogue;
+ * [8 + 8 w + i] = eight time stamps of wave w of workgroup 0 in its fourth chunk (gemm_core_x3w.h).
+ * out72 = HOST array of 72 counters; reset != 0 clears them after the read. */
+int pram_debug_gemm_phases(unsigned long long* out72, int reset);
+
 /* pram_linear_x3_f32 with the activations already split: [A0 | A1] given as fp16 planes (value * 16 = hi + lo, [m][lda]
  * halves) written by the epilogues of pram_linear_x3[p]_f32 / pram_attention_x3_f32 / pram_layernorm_gelu_x3.  Both operands are
  * then staged with plain 16-byte copies (the fp32-input form splits A again in every column tile and is instruction-issue

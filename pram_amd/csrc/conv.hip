@@ -233,11 +233,16 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
     }
     const int nlast = p.cout - 1;
-    int cky = 0, ckx = 0, cci = 0;
+    // K is walked channel chunk by channel chunk with the ks x ks taps innermost: the nine shifted reads of a 32-channel slab
+    // of the tile's input window (one 128-byte line per pixel) follow each other, so eight of them hit the L2 — with the taps
+    // outermost a workgroup came back to a line only after a whole tap (256 KB per workgroup, 8 MB per XCD against 4 MB of L2)
+    // and the 3x3 layers fetched 3.4x their input from HBM (profiles/r02b_pmc_summary.md).  koff = the chunk's offset in the
+    // [ky][kx][ci] rows of the weight matrix.
+    int cky = 0, ckx = 0, cci = 0, koff = 0;
     auto adv = [&](int kt) {
-        if (kt == 0) { cky = ckx = cci = 0; return; }
-        cci += BK;
-        if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
+        if (kt == 0) { cky = ckx = cci = koff = 0; return; }
+        if (++ckx == p.ks) { ckx = 0; if (++cky == p.ks) { cky = 0; cci += BK; } }
+        koff = (cky * p.ks + ckx) * p.cin + cci;
     };
     size_t boff[C::PB];
 #pragma unroll
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
         const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
         return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
-    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
+    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + koff); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 64 * pp) < p.cout; };
     f32x16 acc[MI][2];
     mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, ACT_SCALE, acc);
@@ -298,11 +303,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
     }
     const int nlast = p.cout - 1;
-    int cky = 0, ckx = 0, cci = 0;
+    // K is walked channel chunk by channel chunk with the ks x ks taps innermost: the nine shifted reads of a 32-channel slab
+    // of the tile's input window (one 128-byte line per pixel) follow each other, so eight of them hit the L2 — with the taps
+    // outermost a workgroup came back to a line only after a whole tap (256 KB per workgroup, 8 MB per XCD against 4 MB of L2)
+    // and the 3x3 layers fetched 3.4x their input from HBM (profiles/r02b_pmc_summary.md).  koff = the chunk's offset in the
+    // [ky][kx][ci] rows of the weight matrix.
+    int cky = 0, ckx = 0, cci = 0, koff = 0;
     auto adv = [&](int kt) {
-        if (kt == 0) { cky = ckx = cci = 0; return; }
-        cci += BK;
-        if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
+        if (kt == 0) { cky = ckx = cci = koff = 0; return; }
+        if (++ckx == p.ks) { ckx = 0; if (++cky == p.ks) { cky = 0; cci += BK; } }
+        koff = (cky * p.ks + ckx) * p.cin + cci;
     };
     size_t boff[C::QB];
 #pragma unroll
@@ -315,12 +325,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
         const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
         return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
-    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kt * BK); };
+    auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + koff); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + qrow + C::RQ * pp) < p.cout; };
     f32x16 acc[MI][2];
     auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
     auto bptr = [&](int row, int plane, int kt) -> const _Float16* {
-        return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * p.k + kt * BK;
+        return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * p.k + koff;
     };
     mainloop<MI, WM, WN, false, 0, 1>(smem, adv, la, oka, lb, okb, aptr, bptr, p.k / BK, gemmx3::ACT_SCALE, acc);
 #pragma unroll

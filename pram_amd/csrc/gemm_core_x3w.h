@@ -24,6 +24,13 @@ using gemmx3::swz;
 
 constexpr int BK = 32;
 
+// PRAM_GEMM_ABLATE=4 (profiling only): wave 0 of every workgroup adds the shader-clock cycles it spent per main-loop phase
+// [0] issue + MFMA k-steps  [1] waiting for the chunk's loads (vmcnt)  [2] commit (split + ds_write)  [3] barrier
+// [4] whole main loop  [5] workgroups  [6] epilogue (added by the kernel);  [8 + 8 w + i]: workgroup 0's wave w, chunk 3, time stamp i
+// (0 loop top, 1 loads issued, 2 first k-step issued, 3 second k-step issued, 4 loads landed, 5 commit done, 6 past the
+// barrier).  Read with pram_debug_gemm_phases().
+static __device__ unsigned long long prof[72];
+
 template <int MI, int WM, int WN>
 struct Cfg {
     static constexpr int NT = 64 * WM * WN;
@@ -225,16 +232,44 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
         commit(0, g);
         dma_wait();
         __syncthreads();
+        unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, tl0 = 0ull;
+        if constexpr ((ABL & 4) != 0) tl0 = __builtin_readcyclecounter();
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
+            unsigned long long t0 = 0ull, t1 = 0ull, t2 = 0ull, t3 = 0ull, s1 = 0ull, s2 = 0ull;
+            if constexpr ((ABL & 4) != 0) t0 = __builtin_readcyclecounter();
             if (more && !(ABL & 1)) { adv(kt + 1); issue(kt + 1, g); dma((kt + 1) & 1, kt + 1); }
             __builtin_amdgcn_sched_barrier(0);       // the loads go out first; nothing of commit() (its waits) moves above the MFMAs
+            if constexpr ((ABL & 4) != 0) s1 = __builtin_readcyclecounter();
             kstep(kt & 1, 0);
+            if constexpr ((ABL & 4) != 0) { __builtin_amdgcn_sched_barrier(0); s2 = __builtin_readcyclecounter(); }
             kstep(kt & 1, (ABL & 2) ? 0 : 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 4) != 0) {
+                t1 = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t2 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (more && !(ABL & 1)) commit((kt + 1) & 1, g);
             dma_wait();
+            if constexpr ((ABL & 4) != 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = __builtin_readcyclecounter(); }
             __syncthreads();
+            if constexpr ((ABL & 4) != 0) {
+                const unsigned long long t4 = __builtin_readcyclecounter();
+                ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+                if (blockIdx.x == 0 && kt == 3 && lane == 0) {
+                    unsigned long long* q = &prof[8 + 8 * wave];
+                    q[0] = t0; q[1] = s1; q[2] = s2; q[3] = t1; q[4] = t2; q[5] = t3; q[6] = t4; q[7] = 0ull;
+                }
+            }
+        }
+        if constexpr ((ABL & 4) != 0) {
+            if (tid == 0) {
+                for (int i = 0; i < 4; ++i) atomicAdd(&prof[i], ph[i]);
+                atomicAdd(&prof[4], (unsigned long long)__builtin_readcyclecounter() - tl0);
+                atomicAdd(&prof[5], 1ull);
+            }
         }
     }
 }

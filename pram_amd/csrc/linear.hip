@@ -398,6 +398,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
         auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
         mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc);
     }
+    unsigned long long te0 = 0ull;
+    if constexpr ((ABL & 4) != 0) te0 = __builtin_readcyclecounter();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -405,6 +407,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
     linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
+    if constexpr ((ABL & 4) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) atomicAdd(&gemmx3w::prof[6], (unsigned long long)__builtin_readcyclecounter() - te0);
+    }
 }
 
 // ---------------------------------------------------------------- LayerNorm + GELU
@@ -518,8 +524,9 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
         hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv);
     };
     if (ab == 8) go(linear_x3w_kernel<MI, WM, WN, APLANES, 0, 0>);       // register staging for both operands (no LDS-DMA)
-    else if (ab == 1) go(linear_x3w_kernel<MI, WM, WN, APLANES, 1>);
-    else if (ab == 2) go(linear_x3w_kernel<MI, WM, WN, APLANES, 2>);
+    else if (ab == 1) go(linear_x3w_kernel<MI, WM, WN, APLANES, 1>);      // no staging after the first chunk
+    else if (ab == 2) go(linear_x3w_kernel<MI, WM, WN, APLANES, 2>);      // fragments read once per chunk
+    else if (ab == 4) go(linear_x3w_kernel<MI, WM, WN, APLANES, 4>);      // phase clocks -> pram_debug_gemm_phases
     else go(linear_x3w_kernel<MI, WM, WN, APLANES, 3>);
 }
 
@@ -577,6 +584,18 @@ extern "C" int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda
     if (wn == 2) { if (mi == 2) launch_linear_x3p_t<2, 2>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 2>(p, a, wh, wl, inv, st); }
     else         { if (mi == 2) launch_linear_x3p_t<2, 1>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 1>(p, a, wh, wl, inv, st); }
     return pram_launch_status("pram_linear_x3p_f32");
+}
+
+/* Profiling aid: the per-phase shader-clock totals the wide split-fp16 GEMM accumulates when PRAM_GEMM_ABLATE=4 (see
+   gemm_core_x3w.h); out72 = host array of 72 counters, reset != 0 clears them afterwards. */
+extern "C" int pram_debug_gemm_phases(unsigned long long* out72, int reset) {
+    PRAM_REQUIRE(out72, "pram_debug_gemm_phases: null pointer");
+    if (hipMemcpyFromSymbol(out72, HIP_SYMBOL(gemmx3w::prof), 72 * sizeof(unsigned long long)) != hipSuccess) return pram_launch_status("pram_debug_gemm_phases");
+    if (reset) {
+        unsigned long long z[72] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gemmx3w::prof), z, sizeof(z)) != hipSuccess) return pram_launch_status("pram_debug_gemm_phases");
+    }
+    return PRAM_OK;
 }
 
 static int linear_x3_impl(const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,

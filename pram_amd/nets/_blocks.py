@@ -179,13 +179,25 @@ class PackedCache:
 
     def _packed_get(self, builder):
         dev = next(self.parameters()).device
-        key = str(dev)
+        # the version counters catch in-place edits (optimizer steps, p.mul_() under no_grad); writes through `.data`
+        # bypass them — call refresh_packed() after those
+        ver = 0
+        for t in self.parameters():
+            ver += t._version
+        for t in self.buffers():
+            ver += t._version
+        key = (str(dev), ver)
         cache = self.__dict__.setdefault("_packed_store", {})
         if key not in cache:
             cache.clear()
             with torch.no_grad():
                 cache[key] = builder(dev)
         return cache[key]
+
+    def refresh_packed(self):
+        """Drop the packed / split device copies of the weights; the next forward rebuilds them from the parameters."""
+        self._packed_invalidate()
+        return self
 
     def _packed_invalidate(self):
         self.__dict__.setdefault("_packed_store", {}).clear()      # derived forms (fp16 / split planes) die with the packed tensors

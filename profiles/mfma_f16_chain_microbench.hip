@@ -7,8 +7,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 template <int NACC>
-__global__ __launch_bounds__(256) void k(const _Float16* in, float* out, int iters) {
+__global__ __launch_bounds__(256) void k(const _Float16* in, float* out, int iters, unsigned long long* clk) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     half8 a[4], b[4];
     for (int j = 0; j < 4; ++j)
         for (int i = 0; i < 8; ++i) { a[j][i] = in[(t * 8 + i + 64 * j) & 0xffff]; b[j][i] = in[(t * 8 + i + 17 + 32 * j) & 0xffff]; }
@@ -25,20 +26,26 @@ __global__ __launch_bounds__(256) void k(const _Float16* in, float* out, int ite
     for (int n = 0; n < NACC; ++n)
         for (int e = 0; e < 16; ++e) s += c[n][e];
     out[t] = s;
+    if (t == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = wall_clock64() - r0; }      // s_memtime ticks, 100 MHz ticks
 }
 template <int NACC>
 void run(const _Float16* in, float* out, int bpc, const char* tag) {
     const int blocks = 256 * bpc, iters = 4000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, 500);
+    static unsigned long long* clk = nullptr;
+    if (!clk) hipMalloc(&clk, 16);
+    hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, 500, clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+    hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)blocks * 4 * iters * 8 * 32768.0;
-    printf("%s chains/wave %d, waves/SIMD %d: %.3f ms, %.1f TFLOP/s (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n", tag, NACC, bpc, ms, flops / ms / 1e9,
-           ms * 1e-3 * 2.4e9 / ((double)bpc * iters * 8));
+    unsigned long long hc[2];
+    hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    // workgroup 0's own view: s_memtime ticks per MFMA it issued, and the tick rate against the 100 MHz s_memrealtime
+    printf("%s chains/wave %d, waves/SIMD %d: %.3f ms, %.1f TFLOP/s (%.1f cycles per MFMA per SIMD at 2.4 GHz; s_memtime: %.1f ticks per MFMA of one wave, %.0f MHz tick rate)\n",
+           tag, NACC, bpc, ms, flops / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)bpc * iters * 8), (double)hc[0] / (iters * 8.0), (double)hc[0] / (double)hc[1] * 100.0);
 }
 int main() {
     _Float16 *in; float *out;

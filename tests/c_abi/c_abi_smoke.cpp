@@ -43,6 +43,37 @@ int main() {
     printf("pram_linear_f32     max |err| vs fp64 = %.3e\n", worst);
     if (!(worst < 1e-5)) return 4;
 
+    // ---- pram_linear_x3_f32 (the default precision): the caller splits the weight matrix into two fp16 planes on the host
+    {
+        float wmax = 0.f;
+        for (float e : w) wmax = fmaxf(wmax, fabsf(e));
+        const float w_scale = exp2f(floorf(log2f(16384.0f / wmax)));          // max|w| * w_scale in [2^13, 2^14)
+        std::vector<_Float16> whi(w.size()), wlo(w.size());
+        for (size_t i = 0; i < w.size(); ++i) {
+            const float sv = w[i] * w_scale;
+            whi[i] = (_Float16)sv;
+            wlo[i] = (_Float16)(sv - (float)whi[i]);
+        }
+        void *dwh, *dwl;
+        HIP_OK(hipMalloc(&dwh, whi.size() * 2)); HIP_OK(hipMalloc(&dwl, wlo.size() * 2));
+        HIP_OK(hipMemcpy(dwh, whi.data(), whi.size() * 2, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dwl, wlo.data(), wlo.size() * 2, hipMemcpyHostToDevice));
+        HIP_OK(hipMemset(dout, 0, out.size() * 4));
+        PRAM_OK_(pram_linear_x3_f32(dx, k, k, nullptr, 0, 0, dwh, dwl, w_scale, db, nullptr, 0, dout, n, nullptr, nullptr, 0, m, n,
+                                    1.0f, 0, nullptr, nullptr, 0, st));
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
+        double worst3 = 0.0;
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < n; ++j) {
+                double acc = b[j];
+                for (int t = 0; t < k; ++t) acc += (double)x[i * k + t] * w[j * k + t];
+                worst3 = fmax(worst3, fabs(acc - out[i * n + j]));
+            }
+        printf("pram_linear_x3_f32  max |err| vs fp64 = %.3e\n", worst3);
+        if (!(worst3 < 1e-5)) return 9;
+    }
+
     // ---- pram_attention_f32: 2 sequences x 4 heads x 64, ragged lengths, with and without the split workspace
     const int B = 2, H = 4, T = 200, C = H * 64;
     const int lens_h[2] = {200, 77};

@@ -1,5 +1,5 @@
 """GPU: the C ABI used without Python or torch — a stand-alone C++ program (tests/c_abi/c_abi_smoke.cpp) linked against
-libpram_hip.so with nothing but the HIP runtime, checking linear and attention against fp64 loops, fused == split
+libpram_hip.so with nothing but the HIP runtime, checking linear (fp32 and split-fp16) and attention against fp64 loops, fused == split
 attention bit for bit, and the error-code path."""
 import subprocess
 from pathlib import Path
@@ -20,4 +20,4 @@ def test_c_abi_standalone_program(hip_lib, tmp_path):
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
-    assert "c_abi_smoke ok" in run.stdout and "fused == split" in run.stdout
+    assert "c_abi_smoke ok" in run.stdout and "fused == split" in run.stdout and "pram_linear_x3_f32" in run.stdout

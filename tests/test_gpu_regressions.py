@@ -198,3 +198,30 @@ def test_ragged_linear_touches_only_valid_rows(dev, prec):
     got = ops.layernorm_gelu_(h.clone(), g, bt, lens=lens, t_pad=T).view(S, T, N)
     for s_, n in enumerate(lens.tolist()):
         assert torch.equal(got[s_, :n], ref.view(S, T, N)[s_, :n]) and torch.equal(got[s_, n:], h.view(S, T, N)[s_, n:])
+
+
+def test_packed_weights_follow_in_place_parameter_edits(dev):
+    """The packed / split device copies of the weights are keyed on the parameters' version counters: an in-place edit
+    (optimizer step, p.mul_() under no_grad) must show up in the next forward; refresh_packed() covers writes through .data."""
+    from pram_amd.nets.gml import GML
+    net = GML({})
+    sd = W.make_state_dict("gml", net.state_dict(), seed=7)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    data, _ = H.pair_data(1, 320, 288)
+    before = net.produce_matches(_to(data, dev))["matching_scores0"].clone()
+    heads = [p for n, p in net.named_parameters() if n.startswith("out_proj.") and n.endswith(".weight")]
+    assert heads
+    with torch.no_grad():
+        for p in heads:
+            p.mul_(1.05)
+    sd2 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    ref = R.gml_produce_matches(sd2, data)
+    r = net.produce_matches(_to(data, dev))
+    assert H.maxdiff(r["matching_scores0"], before) > 1e-4
+    assert torch.equal(r["matches0"].cpu(), ref["matches0"]) and H.maxdiff(r["matching_scores0"], ref["matching_scores0"]) < 1e-3
+    for p in heads:
+        p.data.div_(1.05)                    # invisible to the version counter
+    net.refresh_packed()
+    again = net.produce_matches(_to(data, dev))["matching_scores0"]
+    assert H.maxdiff(again, before) < 1e-4

@@ -200,7 +200,7 @@ def test_conv_x3_is_fp32_class(dev):
         e32 = err(ops.conv2d_nhwc(xa, wa, b.to(dev), sc.to(dev), sh.to(dev), precision="f32", **kw), ref)
         ex3 = err(ops.conv2d_nhwc(xa, wa, b.to(dev), sc.to(dev), sh.to(dev), precision="x3", **kw), ref)
         print(f"conv {cin}->{cout} k{ks} s{stride}: |err| f32 {e32:.2e}  x3 {ex3:.2e}")
-        assert ex3 < 5e-6 and ex3 < 4 * e32 + 1e-6
+        assert ex3 < 1e-5 and ex3 < 4 * e32 + 1e-6      # fp32 accumulation over up to 2304 terms: the order of the sum moves the last bits
 
 
 @pytest.mark.parametrize("prec", ["x3", "f32"])
