@@ -79,7 +79,8 @@ __device__ __forceinline__ void dma_tile(_Float16* lds_hi, _Float16* lds_lo, Row
 // APLANES = true : ALoad(p, kt, plane) -> raw uint4 plane[row = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7]
 // BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7];  *Ok: predicates;  Adv as gemm_core_x3.h
 // ABL (profiling only, PRAM_GEMM_ABLATE): bit 0 = no staging after the first chunk (LDS content stale), bit 1 = fragments read
-// once per chunk instead of per k-step.  Results are garbage; the remaining work keeps its shape.
+// once per chunk instead of per k-step, 16 = no A staging (loads, split, ds_write), 32 = no B DMA.  Results are garbage; the
+// remaining work keeps its shape.
 // DMA: 0 = register staging for both operands; 1 = B (weights) by LDS-DMA (bptr(row, plane, kt) -> row pointer at the chunk's k);
 //      2 = A planes by LDS-DMA as well (aptr likewise; APLANES only).  Rows are clamped by the pointer functors; an out-of-range
 //      row is a duplicate whose outputs the epilogue never stores.
@@ -111,7 +112,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
     };
     auto issue = [&](int kt, Regs& g) {
         g.ok = 0u;
-        if constexpr (DMA < 2) {
+        if constexpr (DMA < 2 && !(ABL & 16)) {
 #pragma unroll
             for (int p = 0; p < NA; ++p) {
                 if constexpr (APLANES) { g.ah[p] = la(p, kt, 0); g.al[p] = la(p, kt, 1); }
@@ -126,7 +127,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
     };
     // the DMA part of a chunk's staging: issued with the register loads, lands in LDS buffer `buf` on its own
     auto dma = [&](int buf, int kt) {
-        if constexpr (DMA >= 1) {
+        if constexpr (DMA >= 1 && !(ABL & 32)) {
             auto bp = [&](int row, int plane) { return bptr(row, plane, kt); };
             dma_tile<C::BN, C::NT / 64>(s.bh[buf], s.bl[buf], bp);
         }
@@ -140,7 +141,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
     };
     auto commit = [&](int buf, const Regs& g) {
 #pragma unroll
-        for (int p = 0; p < (DMA < 2 ? NA : 0); ++p) {
+        for (int p = 0; p < ((DMA < 2 && !(ABL & 16)) ? NA : 0); ++p) {
             if constexpr (APLANES) {
                 const int row = qrow + C::RQ * p;
                 uint4 vh = g.ah[p], vl = g.al[p];

@@ -527,6 +527,8 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
     else if (ab == 1) go(linear_x3w_kernel<MI, WM, WN, APLANES, 1>);      // no staging after the first chunk
     else if (ab == 2) go(linear_x3w_kernel<MI, WM, WN, APLANES, 2>);      // fragments read once per chunk
     else if (ab == 4) go(linear_x3w_kernel<MI, WM, WN, APLANES, 4>);      // phase clocks -> pram_debug_gemm_phases
+    else if (ab == 16) go(linear_x3w_kernel<MI, WM, WN, APLANES, 16>);    // no A staging
+    else if (ab == 32) go(linear_x3w_kernel<MI, WM, WN, APLANES, 32>);    // no B DMA
     else go(linear_x3w_kernel<MI, WM, WN, APLANES, 3>);
 }
 
