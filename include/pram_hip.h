@@ -181,6 +181,14 @@ int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const voi
                           const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
                           float scale, int kv_shift, void* stream);
 
+/* Column means of the soft-max matrix of the pram_attention_x3_f32 call that produced lse2 (AdaGML's token scores,
+ * nets/adagml.py:92-104): colmean[kb][j] = mean over heads and over the q_lens[b] query rows of softmax_row(scale q k^T)[i][j],
+ * kb = (b + kv_shift) % batch, [batch][n_max] fp32; entries j >= k_lens[kb] are left untouched.  q / k: the same split planes,
+ * lse2: [batch][heads][m_max] (log2 domain).  Second Q K^T pass on the fp16 matrix pipe, three MFMAs per product; no atomics. */
+int pram_attention_x3_colmean_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
+                                  const float* lse2, float* colmean, const int* q_lens, const int* k_lens, int batch,
+                                  int heads, int m_max, int n_max, float scale, int kv_shift, void* stream);
+
 /* Row-major value planes [seqs * t_max][ldv] (head h at columns 64 h ..) -> the transposed, key-permuted planes
  * pram_attention_x3_f32 stages with plain 16-byte copies: [seqs][heads][64][tv], tv = t_max rounded up to 64, position of
  * token t = 64 (t / 64) + perm(t % 64) (the order in which the S^T accumulator registers hold the keys); tokens

@@ -327,7 +327,136 @@ __global__ __launch_bounds__(256) void vt_kernel(VtArgs p) {
     *reinterpret_cast<half8*>(p.ol + dst + 8) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16 + 8]);
 }
 
+// ---------------------------------------------------------------- column means of the attention matrix (AdaGML)
+// colmean[kb][j] = 1 / (H m_b) * sum_h sum_i exp2(scale2 * q_i . k_j - lse2[b, h, i])   (nets/adagml.py:92-104: the mean over heads
+// and query rows of the soft-max matrix, one number per key token — what the pooling MLP turns into a keep / prune logit).
+// Second pass over Q K^T with the row normalisers of the first (lse2 of attention_x3_kernel); the operands are the same split
+// planes, three MFMAs per product.  One workgroup = 128 keys (32 per wave, their K fragments live in registers as the MFMA's
+// row operand); the queries stream through LDS in 64-row tiles as the column operand, so a lane owns one query per 32-column
+// block — its lse2 is one scalar load — and the per-key sums accumulate in registers across the whole loop; lanes are
+// combined once at the end.  No atomics: the result does not depend on the launch geometry.
+struct ColArgsX {
+    const _Float16* qh; const _Float16* ql; const _Float16* kh; const _Float16* kl;
+    const float* lse2; float* colmean;
+    const int* q_lens; const int* k_lens;
+    int ldq, ldk, batch, heads, m_max, n_max;
+    float scale2;
+    int kv_shift;
+};
+
+__global__ __launch_bounds__(256, 2) void colmean_x3_kernel(ColArgsX p) {
+    __shared__ __attribute__((aligned(16))) _Float16 sqh[2][BKV * D];
+    __shared__ __attribute__((aligned(16))) _Float16 sql[2][BKV * D];
+    const int b = blockIdx.y;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
+    if ((int)blockIdx.x * 128 >= klen) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int key0 = blockIdx.x * 128 + wave * 32;
+    const int lrow = tid >> 3, lseg = tid & 7;
+    const int nqt = (qlen + BKV - 1) / BKV;
+
+    float cacc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cacc[e] = 0.f;
+
+    half8 grh[2], grl[2];
+    // Q rows beyond qlen are duplicates of the last valid row: their (finite) scores meet lse2 = +inf below
+    auto gload = [&](int head, int qt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const size_t qi = (size_t)min(qt * BKV + lrow + 32 * pp, qlen - 1);
+            const size_t off = ((size_t)b * p.m_max + qi) * p.ldq + head * D + lseg * 8;
+            grh[pp] = *reinterpret_cast<const half8*>(p.qh + off);
+            grl[pp] = *reinterpret_cast<const half8*>(p.ql + off);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row = lrow + 32 * pp;
+            const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
+            *reinterpret_cast<half8*>(&sqh[buf][off]) = grh[pp];
+            *reinterpret_cast<half8*>(&sql[buf][off]) = grl[pp];
+        }
+    };
+    const int total = p.heads * nqt;      // (head, q tile) steps, double buffered across head boundaries
+    if (total > 0) {
+        gload(0, 0);
+        lstore(0);
+    }
+    __syncthreads();
+    half8 kh[4], kl[4];
+    int head = 0, qt = 0;
+    for (int it = 0; it < total; ++it) {
+        const int cur = it & 1;
+        if (qt == 0) {
+            const size_t koff = ((size_t)kb * p.n_max + min(key0 + r, klen - 1)) * p.ldk + head * D;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                kh[c] = *reinterpret_cast<const half8*>(p.kh + koff + c * 16 + h * 8);
+                kl[c] = *reinterpret_cast<const half8*>(p.kl + koff + c * 16 + h * 8);
+            }
+        }
+        int nhead = head, nqt_ = qt + 1;
+        if (nqt_ == nqt) { nqt_ = 0; ++nhead; }
+        const bool more = it + 1 < total;
+        if (more) gload(nhead, nqt_);
+        const float* lse = p.lse2 + ((size_t)b * p.heads + head) * p.m_max;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qi = qt * BKV + t * 32 + r;
+            const float l2 = (qi < qlen) ? lse[qi] : INFINITY;
+            f32x16 st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;
+                const half8 qh = *reinterpret_cast<const half8*>(&sqh[cur][(t * 32 + r) * D + slot]);
+                const half8 ql = *reinterpret_cast<const half8*>(&sql[cur][(t * 32 + r) * D + slot]);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[c], qh, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], ql, st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], qh, st, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cacc[e] += __builtin_amdgcn_exp2f(fmaf(st[e], p.scale2, -l2));
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        head = nhead;
+        qt = nqt_;
+    }
+    const float norm = qlen > 0 ? 1.0f / ((float)p.heads * (float)qlen) : 0.f;      // no queries: reported as 0, not NaN
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float v = cacc[e];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int key = key0 + key_of(e, h);
+        if (r == 0 && key < klen) p.colmean[(size_t)kb * p.n_max + key] = v * norm;
+    }
+}
+
 }  // namespace
+
+/* Column means of the soft-max matrix of pram_attention_x3_f32 (AdaGML's token scores): colmean[kb][j] = mean over heads and
+   over the q_lens[b] query rows of softmax_row(scale q k^T)[i][j], kb = (b + kv_shift) % batch, keys j >= k_lens[kb] untouched.
+   q / k: the split planes the attention call used; lse2: its row log-sum-exps (log2 domain), [batch][heads][m_max]. */
+extern "C" int pram_attention_x3_colmean_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
+                                             const float* lse2, float* colmean, const int* q_lens, const int* k_lens, int batch,
+                                             int heads, int m_max, int n_max, float scale, int kv_shift, void* stream) {
+    PRAM_REQUIRE(q_hi && q_lo && k_hi && k_lo && lse2 && colmean, "pram_attention_x3_colmean_f32: null pointer");
+    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0, "pram_attention_x3_colmean_f32: ld of the fp16 planes must be a multiple of 8");
+    PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_x3_colmean_f32: bad sizes");
+    if (batch == 0 || n_max == 0) return PRAM_OK;
+    ColArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, lse2, colmean, q_lens, k_lens,
+               ldq, ldk, batch, heads, m_max, n_max, scale * LOG2E / (IN_SCALE * IN_SCALE), kv_shift};
+    hipLaunchKernelGGL(colmean_x3_kernel, dim3(cdiv(n_max, 128), batch), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_x3_colmean_f32");
+}
 
 /* Value planes [seqs * t_max][ldv] (head h at columns 64 h .., as pram_linear_x3_f32 writes them) -> transposed, key-permuted
    planes [seqs][heads][64][tv], tv = t_max rounded up to a multiple of 64; tokens t >= lens[seq] (NULL = t_max) become zeros. */

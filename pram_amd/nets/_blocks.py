@@ -102,13 +102,12 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
     scale = DH ** -0.5
     if _split_path():
         # split-fp16 path: the projection writes q | k | v as (hi, lo) planes (plus fp32 when the column means need q / k)
-        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="also" if want_colmean else "only",
-                             lens=lens, t_pad=T)
+        _, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="only", lens=lens, t_pad=T)
         q3, k3 = _cols(pl, 0, hid), _cols(pl, hid, 2 * hid)
         v3 = ops.value_planes_t(_cols(pl, 2 * hid, 3 * hid), S, HEADS, T, lens)
         if want_colmean:
             ctx, lse = ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens, want_lse=True)
-            col = ops.attention_colmean(qkv[:, :hid], qkv[:, hid:2 * hid], lse, S, HEADS, T, T, scale, lens, lens)
+            col = ops.attention_colmean_x3(q3, k3, lse, S, HEADS, T, T, scale, lens, lens)
             return _mlp_tail(x, ctx, p, lens, T), col
         return _mlp_tail(x, ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens), p, lens, T)
     if _half_path() and not want_colmean:
@@ -133,12 +132,12 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     hid = HEADS * DH
     scale = DH ** -0.5     # (dh^-1/4)^2
     if _split_path():
-        qkv, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="also" if want_colmean else "only", lens=lens, t_pad=T)
+        _, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="only", lens=lens, t_pad=T)
         qk3 = _cols(pl, 0, hid)
         v3 = ops.value_planes_t(_cols(pl, hid, 2 * hid), 2 * B, HEADS, T, lens)
         if want_colmean:
             ctx, lse = ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, want_lse=True, kv_shift=B)
-            col = ops.attention_cross_colmean(qkv[:, :hid], lse, B, HEADS, T, scale, lens)
+            col = ops.attention_colmean_x3(qk3, qk3, lse, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
             return _mlp_tail(x, ctx, p, lens, T), col[:B], col[B:]
         return _mlp_tail(x, ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B), p, lens, T)
     if _half_path() and not want_colmean:

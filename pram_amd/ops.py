@@ -400,6 +400,22 @@ def attention_x3(q, k, vt, batch: int, heads: int, m_max: int, n_max: int, scale
     return (out, lse) if want_lse else out
 
 
+def attention_colmean_x3(q, k, lse2: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int, scale: float,
+                         q_lens=None, k_lens=None, kv_shift: int = 0) -> torch.Tensor:
+    """Column means of the soft-max matrix attention_x3 just produced (its q / k planes, its lse) -> [batch, n_max] fp32, row
+    (b + kv_shift) % batch holding the means over sequence b's queries; keys beyond their length read 0."""
+    L = _lib.load()
+    for pair in (q, k):
+        for t in pair:
+            assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
+        assert pair[0].stride(0) == pair[1].stride(0)
+    out = torch.zeros(batch, n_max, device=lse2.device, dtype=torch.float32)
+    _lib.check(L.pram_attention_x3_colmean_f32(_p(q[0]), _p(q[1]), q[0].stride(0), _p(k[0]), _p(k[1]), k[0].stride(0), _p(lse2), _p(out),
+                                               _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift), _st()),
+               "pram_attention_x3_colmean_f32")
+    return out
+
+
 def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t_max: int, scale: float,
                     lens: Optional[torch.Tensor] = None, want_lse: bool = False, out: Optional[torch.Tensor] = None,
                     precision: Optional[str] = None):

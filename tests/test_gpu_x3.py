@@ -182,6 +182,61 @@ def test_attention_x3_spike_and_empty(dev):
     assert float(out0.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,M,N,ragged", [(2, 640, 640, False), (3, 300, 517, True), (2, 2048, 2048, True)])
+def test_attention_colmean_x3_vs_fp64(dev, B, M, N, ragged):
+    """AdaGML's token scores on the split path: the mean over heads and query rows of the soft-max matrix, from the planes and
+    the row log-sum-exps of the attention call — against fp64, next to the exact-fp32 kernel; ragged lengths, an empty query set."""
+    from pram_amd import ops
+    Hh = 4
+    q = rnd(15, "cm/q", (B, M, Hh * 64), 1.2)
+    k = rnd(15, "cm/k", (B, N, Hh * 64), 1.2)
+    v = rnd(15, "cm/v", (B, N, Hh * 64))
+    qlens = [M - 37 * i for i in range(B)] if ragged else [M] * B
+    klens = [N - 61 * i for i in range(B)] if ragged else [N] * B
+    if ragged:
+        qlens[-1] = 0                    # no queries: the means are reported as 0
+    scale = 0.125
+    sp = lambda t, L: t.view(B, L, Hh, 64).permute(0, 2, 1, 3).double()
+    s = torch.einsum("bhid,bhjd->bhij", sp(q, M), sp(k, N)) * scale
+    ref = torch.zeros(B, N, dtype=torch.float64)
+    for b in range(B):
+        if qlens[b] > 0:
+            pr = torch.softmax(s[b, :, :qlens[b], :klens[b]], -1)
+            ref[b, :klens[b]] = pr.mean(dim=(0, 1))
+    qd, kd, vd = q.view(B * M, -1).to(dev), k.view(B * N, -1).to(dev), v.view(B * N, -1).to(dev)
+    ql = torch.tensor(qlens, dtype=torch.int32, device=dev)
+    kl = torch.tensor(klens, dtype=torch.int32, device=dev)
+    pq, pk = _planes(ops, qd), _planes(ops, kd)
+    _, lse = ops.attention_x3(pq, pk, ops.value_planes_t(_planes(ops, vd), B, Hh, N, kl), B, Hh, M, N, scale, ql, kl, want_lse=True)
+    cx3 = ops.attention_colmean_x3(pq, pk, lse, B, Hh, M, N, scale, ql, kl)
+    _, lse32 = ops.attention(qd, kd, vd, B, Hh, M, N, scale, ql, kl, want_lse=True, precision="f32")
+    c32 = ops.attention_colmean(qd, kd, lse32, B, Hh, M, N, scale, ql, kl)
+    assert torch.isfinite(cx3).all()
+    ex3, e32 = err(cx3, ref), err(c32, ref)
+    rel = ex3 / float(ref.max())
+    print(f"colmean B{B} {M}x{N}: |err| f32 {e32:.2e}  x3 {ex3:.2e} (largest mean {float(ref.max()):.2e})")
+    assert rel < 2e-5 and ex3 < 4 * e32 + 1e-8
+    for b in range(B):
+        assert float(cx3[b, klens[b]:].abs().max() if klens[b] < N else 0.0) == 0.0
+
+
+def test_attention_colmean_x3_cross_equals_two_directions(dev):
+    from pram_amd import ops
+    B, T = 2, 384
+    qk = rnd(16, "cmx/qk", (2 * B * T, 256), 1.1).to(dev)
+    v = rnd(16, "cmx/v", (2 * B * T, 256)).to(dev)
+    lens = torch.tensor([384, 300, 200, 384], dtype=torch.int32, device=dev)
+    pq, pv = _planes(ops, qk), _planes(ops, v)
+    _, lse = ops.attention_x3(pq, pq, ops.value_planes_t(pv, 2 * B, 4, T, lens), 2 * B, 4, T, T, 0.125, lens, lens, want_lse=True, kv_shift=B)
+    both = ops.attention_colmean_x3(pq, pq, lse, 2 * B, 4, T, T, 0.125, lens, lens, kv_shift=B)
+    half = lambda pl, lo, hi: (pl[0][lo * T:hi * T], pl[1][lo * T:hi * T])
+    l0, l1 = lens[:B].contiguous(), lens[B:].contiguous()
+    # queries of set 0 over the keys of set 1 -> one mean per set-1 token (rows B..2B-1), and the other way round
+    c1 = ops.attention_colmean_x3(half(pq, 0, B), half(pq, B, 2 * B), lse[:B].contiguous(), B, 4, T, T, 0.125, l0, l1)
+    c0 = ops.attention_colmean_x3(half(pq, B, 2 * B), half(pq, 0, B), lse[B:].contiguous(), B, 4, T, T, 0.125, l1, l0)
+    assert torch.equal(both[B:], c1) and torch.equal(both[:B], c0)
+
+
 def test_conv_x3_is_fp32_class(dev):
     from pram_amd import ops
     from pram_amd.nets.sfd2 import ResNet4x
