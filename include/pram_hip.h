@@ -248,11 +248,12 @@ int pram_dual_softmax_match_f32(const float* dist, int ldd, const int* m_lens, c
  * check_if_stop numerator).  If lens_in[s] >= n_min_tokens the tokens with conf > thr are compacted,
  * order preserved, into x_out / cos_out / sin_out / ind_out (else all are copied); lens_out[s] = kept.
  * x [sets][t_max][ldx], cos/sin [sets][t_max][32], ind [sets][t_max] (original token ids).
- * Out-of-place only.  conf_out (optional) [sets][t_max] receives the confidences. */
+ * Out-of-place only; rows at and beyond lens_out[s] of the outputs are not written.  conf_out (optional) [sets][t_max]
+ * receives the confidences.  row_map: scratch, int32 [sets][t_max] (source row of every destination row). */
 int pram_adagml_prune_f32(const float* conf_logit, float thr, int n_min_tokens, const int* lens_in,
                           const float* x_in, const float* cos_in, const float* sin_in, const int* ind_in,
                           float* x_out, float* cos_out, float* sin_out, int* ind_out, int* lens_out,
-                          int* n_below, float* conf_out, int sets, int t_max, int ldx, void* stream);
+                          int* n_below, float* conf_out, int* row_map, int sets, int t_max, int ldx, void* stream);
 
 /* Scatter the matches of the pruned sets back to full size (nets/adagml.py:382-396):
  * out_matches[b][ind0[i]] = ind1[matches0[i]] where matches0[i] >= 0; out_scores[b][ind0[i]] = mscores0[i].

@@ -46,7 +46,7 @@ _SIGS = {
     "pram_sinkhorn_workspace_bytes": (SZ, [I, I, I]),
     "pram_sinkhorn_match_f32": (I, [P, I, P, P, P, I, F, P, I, P, P, P, P, I, I, I, P, P]),
     "pram_dual_softmax_match_f32": (I, [P, I, P, P, P, F, P, I, P, P, P, P, I, I, I, P, P]),
-    "pram_adagml_prune_f32": (I, [P, F, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "pram_adagml_prune_f32": (I, [P, F, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "pram_adagml_scatter_f32": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "pram_conv2d_nhwc_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),
     "pram_conv2d_nhwc_f16_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),

@@ -1,5 +1,5 @@
 // AdaGML token pruning and result scatter (nets/adagml.py:354-372,382-396,516-531).
-// Latency-bound bookkeeping: one workgroup per token set.
+// The bookkeeping (scan) runs one workgroup per token set; the row copies run on the whole chip.
 #include "common.h"
 #include <math.h>
 
@@ -34,16 +34,19 @@ struct PruneArgs {
     const float* logit; float thr; int n_min;
     const int* lens_in; const float* x_in; const float* cos_in; const float* sin_in; const int* ind_in;
     float* x_out; float* cos_out; float* sin_out; int* ind_out; int* lens_out; int* n_below; float* conf_out;
+    int* row_map;
     int t_max, ldx;
 };
 
-__global__ __launch_bounds__(PT) void prune_kernel(PruneArgs p) {
-    __shared__ int dst[T_MAX];
+// Pass 1, one workgroup per token set (latency-bound bookkeeping): confidences, the two counts, and the source row of every
+// surviving destination row: row_map[s][d] = t for d < lens_out[s].
+__global__ __launch_bounds__(PT) void prune_scan_kernel(PruneArgs p) {
     __shared__ int sbuf[17];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int len = p.lens_in ? p.lens_in[s] : p.t_max;
     const bool do_prune = len >= p.n_min;
     const float* lg = p.logit + (size_t)s * p.t_max;
+    int* map = p.row_map + (size_t)s * p.t_max;
     int kept = 0, below = 0;
     for (int base = 0; base < len; base += PT) {
         const int t = base + tid;
@@ -58,20 +61,30 @@ __global__ __launch_bounds__(PT) void prune_kernel(PruneArgs p) {
         int tot, totb;
         const int pos = blk_scan(keep ? 1 : 0, sbuf, &tot);
         blk_scan(bl, sbuf, &totb);
-        if (t < len) dst[t] = keep ? kept + pos : -1;
+        if (keep) map[kept + pos] = t;
         kept += tot;
         below += totb;
     }
-    __syncthreads();
     if (tid == 0) {
         p.lens_out[s] = kept;
         p.n_below[s] = below;
     }
-    const int lane = tid & 63, wave = tid >> 6;
+}
+
+// Pass 2, the whole chip: one wave per destination row (x row = ldx floats, cos / sin 32 floats each, the original token id).
+constexpr int GR = 16;      // destination rows per workgroup (4 waves x 4 rows)
+__global__ __launch_bounds__(256) void prune_gather_kernel(PruneArgs p) {
+    const int s = blockIdx.y;
+    const int kept = p.lens_out[s];
+    const int d0 = blockIdx.x * GR;
+    if (d0 >= kept) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t sx = (size_t)s * p.t_max;
-    for (int t = wave; t < len; t += PT / 64) {
-        const int d = dst[t];
-        if (d < 0) continue;
+#pragma unroll
+    for (int i = 0; i < GR / 4; ++i) {
+        const int d = d0 + wave * (GR / 4) + i;
+        if (d >= kept) break;
+        const int t = p.row_map[sx + d];
         const float* xi = p.x_in + (sx + t) * p.ldx;
         float* xo = p.x_out + (sx + d) * p.ldx;
         for (int c = lane * 4; c < p.ldx; c += 256) *reinterpret_cast<float4*>(xo + c) = *reinterpret_cast<const float4*>(xi + c);
@@ -102,15 +115,16 @@ __global__ void scatter_kernel(const long long* __restrict__ m0, const float* __
 extern "C" int pram_adagml_prune_f32(const float* conf_logit, float thr, int n_min_tokens, const int* lens_in,
                                      const float* x_in, const float* cos_in, const float* sin_in, const int* ind_in,
                                      float* x_out, float* cos_out, float* sin_out, int* ind_out, int* lens_out,
-                                     int* n_below, float* conf_out, int sets, int t_max, int ldx, void* stream) {
-    PRAM_REQUIRE(conf_logit && x_in && cos_in && sin_in && ind_in && x_out && cos_out && sin_out && ind_out && lens_out && n_below,
+                                     int* n_below, float* conf_out, int* row_map, int sets, int t_max, int ldx, void* stream) {
+    PRAM_REQUIRE(conf_logit && x_in && cos_in && sin_in && ind_in && x_out && cos_out && sin_out && ind_out && lens_out && n_below && row_map,
                  "pram_adagml_prune_f32: null pointer");
     PRAM_REQUIRE(t_max <= T_MAX && ldx % 4 == 0, "pram_adagml_prune_f32: t_max=%d exceeds %d or ldx not a multiple of 4", t_max, T_MAX);
     PRAM_REQUIRE(x_in != x_out, "pram_adagml_prune_f32: in-place compaction is not supported (ping-pong the buffers)");
-    if (sets == 0) return PRAM_OK;
+    if (sets == 0 || t_max == 0) return PRAM_OK;
     PruneArgs p{conf_logit, thr, n_min_tokens, lens_in, x_in, cos_in, sin_in, ind_in, x_out, cos_out, sin_out, ind_out,
-                lens_out, n_below, conf_out, t_max, ldx};
-    hipLaunchKernelGGL(prune_kernel, dim3(sets), dim3(PT), 0, (hipStream_t)stream, p);
+                lens_out, n_below, conf_out, row_map, t_max, ldx};
+    hipLaunchKernelGGL(prune_scan_kernel, dim3(sets), dim3(PT), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(prune_gather_kernel, dim3(cdiv(t_max, GR), sets), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_adagml_prune_f32");
 }
 

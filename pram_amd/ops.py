@@ -541,12 +541,15 @@ def adagml_prune(logit, thr, n_min_tokens, lens_in, x, cos, sin, ind, want_conf=
     L = _lib.load()
     S, T = logit.shape
     ldx = x.shape[-1]
-    x_o, cos_o, sin_o, ind_o = torch.zeros_like(x), torch.zeros_like(cos), torch.zeros_like(sin), torch.zeros_like(ind)
-    lens_o = torch.zeros(S, device=x.device, dtype=torch.int32)
-    n_below = torch.zeros(S, device=x.device, dtype=torch.int32)
+    # rows at and beyond the new length of a set are never written — and never read: every consumer is ragged (lens)
+    x_o, cos_o, sin_o, ind_o = torch.empty_like(x), torch.empty_like(cos), torch.empty_like(sin), torch.zeros_like(ind)
+    lens_o = torch.empty(S, device=x.device, dtype=torch.int32)
+    n_below = torch.empty(S, device=x.device, dtype=torch.int32)
     conf = torch.zeros(S, T, device=x.device, dtype=torch.float32) if want_conf else None
+    row_map = torch.empty(S, T, device=x.device, dtype=torch.int32)
     _lib.check(L.pram_adagml_prune_f32(_p(logit), float(thr), int(n_min_tokens), _p(lens_in), _p(x), _p(cos), _p(sin), _p(ind),
-                                       _p(x_o), _p(cos_o), _p(sin_o), _p(ind_o), _p(lens_o), _p(n_below), _p(conf), S, T, ldx, _st()),
+                                       _p(x_o), _p(cos_o), _p(sin_o), _p(ind_o), _p(lens_o), _p(n_below), _p(conf), _p(row_map),
+                                       S, T, ldx, _st()),
                "pram_adagml_prune_f32")
     return x_o, cos_o, sin_o, ind_o, lens_o, n_below, conf
 
