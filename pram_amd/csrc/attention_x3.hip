@@ -283,6 +283,299 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (the default).  The kernel above is bound by its soft-max arithmetic: per 64-key tile a wave
+// issues 40 MFMAs (1 280 matrix cycles) and ~1 000 cycles of VALU work (32 v_exp_f32 at quarter rate, max, scale, convert, sum,
+// rescale), strictly one after the other — S must be complete before the soft-max, P before P V — so within a wave the matrix
+// pipe idles through the whole soft-max, and only the second wave of the SIMD can fill the gap (PMC: MfmaUtil 45 %).
+// Here the scores of tile j + 1 are multiplied WHILE the soft-max of tile j runs: the 24 MFMAs of S_{j+1} and the VALU
+// instructions of softmax(S_j) sit in one scheduling region and are interleaved one MFMA : six VALU (sched_group_barrier), so a
+// wave keeps both pipes busy on its own.  Costs: a second 32-register score tile, and K staged one tile ahead of V (K_{j+2} and
+// V_{j+1} land while K_{j+1} and V_j are read: same 64 KB of LDS).  The arithmetic — and every bit of the result — is that of
+// the kernel above; the soft-max is written with packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32).
+template <bool PSPLIT>
+__global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
+    __shared__ Smem s;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const int nblk = p.batch * p.heads * p.q_tiles;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int qt = id % p.q_tiles;
+    const int bh = id / p.q_tiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
+    if (qt * BQ >= qlen) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qt * BQ + wave * QW;
+    const bool wave_active = q0 < qlen;
+    const int qrow = q0 + r;
+    const bool q_ok = qrow < qlen;
+    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip)
+        if (q_ok) {
+            float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = 0.f;
+        }
+        return;
+    }
+
+    const size_t qoff = ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
+    const size_t koff = (size_t)kb * p.n_max * p.ldk + head * D;
+    const size_t voff = ((size_t)kb * p.heads + head) * D * p.tv;
+
+    half8 qh[4], ql[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qh[c] = *reinterpret_cast<const half8*>(p.qh + qoff + c * 16 + h * 8);
+        ql[c] = *reinterpret_cast<const half8*>(p.ql + qoff + c * 16 + h * 8);
+        if (!q_ok)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qh[c][i] = (_Float16)0.f; ql[c][i] = (_Float16)0.f; }
+    }
+
+    const int lrow = tid >> 3, lseg = tid & 7;
+    half8 krh[2], krl[2], vrh[2], vrl[2];
+    auto gload_k = [&](int kt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const size_t kc = (size_t)min(kt * BKV + lrow + 32 * pp, klen - 1);
+            krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
+            krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
+        }
+    };
+    auto gload_v = [&](int kt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const size_t vo = voff + (size_t)(lrow + 32 * pp) * p.tv + kt * BKV + lseg * 8;
+            vrh[pp] = *reinterpret_cast<const half8*>(p.vh + vo);
+            vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
+        }
+    };
+    auto lstore_k = [&](int buf) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row = lrow + 32 * pp;
+            const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
+            *reinterpret_cast<half8*>(&s.kh[buf][off]) = krh[pp];
+            *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
+        }
+    };
+    auto lstore_v = [&](int buf) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row = lrow + 32 * pp;
+            const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
+            *reinterpret_cast<half8*>(&s.vth[buf][off]) = vrh[pp];
+            *reinterpret_cast<half8*>(&s.vtl[buf][off]) = vrl[pp];
+        }
+    };
+
+    struct KFrag { half8 h0, h1, l0, l1; };
+    auto kload = [&](int buf, int c, KFrag& f) {
+        const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;
+        f.h0 = *reinterpret_cast<const half8*>(&s.kh[buf][r * D + slot]);
+        f.h1 = *reinterpret_cast<const half8*>(&s.kh[buf][(32 + r) * D + slot]);
+        f.l0 = *reinterpret_cast<const half8*>(&s.kl[buf][r * D + slot]);
+        f.l1 = *reinterpret_cast<const half8*>(&s.kl[buf][(32 + r) * D + slot]);
+    };
+    auto kmma = [&](f32x16 (&st)[2], int c, const KFrag& f) {
+        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, qh[c], st[0], 0, 0, 0);
+        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, qh[c], st[1], 0, 0, 0);
+        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ql[c], st[0], 0, 0, 0);
+        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ql[c], st[1], 0, 0, 0);
+        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, qh[c], st[0], 0, 0, 0);
+        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, qh[c], st[1], 0, 0, 0);
+    };
+    struct VFrag { half8 h0, h1, l0, l1; };
+    auto vload = [&](int buf, int t, int u, VFrag& f) {
+        const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
+        f.h0 = *reinterpret_cast<const half8*>(&s.vth[buf][r * BKV + slot]);
+        f.h1 = *reinterpret_cast<const half8*>(&s.vth[buf][(32 + r) * BKV + slot]);
+        f.l0 = *reinterpret_cast<const half8*>(&s.vtl[buf][r * BKV + slot]);
+        f.l1 = *reinterpret_cast<const half8*>(&s.vtl[buf][(32 + r) * BKV + slot]);
+    };
+
+    const int nkt = (klen + BKV - 1) / BKV;
+    float m_run = -1.0e30f, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+    half8 ph[2][2], pl[2][2];
+
+    // softmax(S) of one tile: running max / sum, the probabilities as fp16 (and their residuals when PSPLIT), O rescaled
+    auto softmax = [&](f32x16 (&st)[2]) {
+        float tmax = st[0][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax * p.scale2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float shift = P_EXP_SHIFT - m_new;
+        const f2 sc2 = {p.scale2, p.scale2}, sh2 = {shift, shift}, al2 = {alpha, alpha};
+        const half2_t ones = {(_Float16)1.f, (_Float16)1.f};
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f2 y = __builtin_elementwise_fma((f2){st[t][e], st[t][e + 1]}, sc2, sh2);      // one rounding, like fmaf
+                const float p0 = __builtin_amdgcn_exp2f(y[0]);       // argument <= 14
+                const float p1 = __builtin_amdgcn_exp2f(y[1]);
+                const half2_t pk = {(_Float16)p0, (_Float16)p1};
+                ph[t][e >> 3][e & 7] = pk[0];
+                ph[t][e >> 3][(e & 7) + 1] = pk[1];
+                if constexpr (PSPLIT) {
+                    psum += p0 + p1;
+                    pl[t][e >> 3][e & 7] = (_Float16)(p0 - (float)pk[0]);
+                    pl[t][e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)pk[1]);
+                } else {
+                    psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
+                }
+            }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f2 o = (f2){oacc[dn][e], oacc[dn][e + 1]} * al2;
+                oacc[dn][e] = o[0];
+                oacc[dn][e + 1] = o[1];
+            }
+    };
+    auto vmma = [&](int t, int u, const VFrag& f) {
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
+        if constexpr (PSPLIT) {
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
+        }
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ph[t][u], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ph[t][u], oacc[1], 0, 0, 0);
+    };
+    auto pv = [&](int vbuf) {
+        VFrag va, vb;
+        vload(vbuf, 0, 0, va);
+        vload(vbuf, 0, 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        vmma(0, 0, va);
+        vload(vbuf, 1, 0, va);
+        __builtin_amdgcn_sched_barrier(0);
+        vmma(0, 1, vb);
+        vload(vbuf, 1, 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        vmma(1, 0, va);
+        __builtin_amdgcn_sched_barrier(0);
+        vmma(1, 1, vb);
+    };
+
+    // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own
+    gload_k(0);
+    lstore_k(0);
+    gload_v(0);
+    if (nkt > 1) gload_k(1);
+    lstore_v(0);
+    if (nkt > 1) lstore_k(1);
+    __syncthreads();
+    f32x16 sa[2], sb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { sa[0][e] = 0.f; sa[1][e] = 0.f; }
+    if (wave_active) {
+        KFrag fa, fb;
+        kload(0, 0, fa);
+        kload(0, 1, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        kmma(sa, 0, fa);
+        kload(0, 2, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        kmma(sa, 1, fb);
+        kload(0, 3, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        kmma(sa, 2, fa);
+        kmma(sa, 3, fb);
+    }
+
+    // tile j (not the last): S_{j+1} = K_{j+1} Q^T interleaved with softmax(S_j), then O += V_j P_j; K_{j+2} and V_{j+1} staged
+    auto mid = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+        const int kbuf = (j + 1) & 1, vbuf = j & 1;
+        const bool more_k = j + 2 < nkt;
+        gload_v(j + 1);
+        if (more_k) gload_k(j + 2);
+        if (wave_active) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
+            KFrag fa, fb;
+            kload(kbuf, 0, fa);
+            kload(kbuf, 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sn, 0, fa);
+            kload(kbuf, 2, fa);
+            kmma(sn, 1, fb);
+            kload(kbuf, 3, fb);
+            kmma(sn, 2, fa);
+            kmma(sn, 3, fb);
+            softmax(sc);
+            // one MFMA, then VALU work of the soft-max in its shadow; the eight fragment reads go out with the first groups
+#pragma unroll
+            for (int g = 0; g < 24; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pv(vbuf);
+        }
+        lstore_v((j + 1) & 1);
+        if (more_k) lstore_k(j & 1);
+        __syncthreads();
+    };
+    int j = 0;
+    for (; j + 2 < nkt; j += 2) {
+        mid(j, sa, sb);
+        mid(j + 1, sb, sa);
+    }
+    bool in_a = true;
+    if (j + 1 < nkt) { mid(j, sa, sb); in_a = false; ++j; }
+    if (!wave_active) return;
+    // last tile: mask the keys beyond klen, soft-max, P V
+    auto last = [&](f32x16 (&sc)[2]) {
+        if (klen & (BKV - 1)) {
+            const int kbase = (nkt - 1) * BKV;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kbase + t * 32 + key_of(e, h) >= klen) sc[t][e] = -INFINITY;
+        }
+        softmax(sc);
+        __builtin_amdgcn_sched_barrier(0);
+        pv((nkt - 1) & 1);
+    };
+    if (in_a) last(sa); else last(sb);
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (1.0f / IN_SCALE) / l_tot;
+    if (q_ok) {
+        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
+                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
+            }
+        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + (log2f(l_tot) - P_EXP_SHIFT);
+    }
+}
+
 // V^T planes for attention_x3_kernel: [seq][head][64 dims][tv positions] fp16, position = 64 * (t / 64) + pos_of_key(t % 64),
 // zeros for t >= lens[seq] (a masked key then meets a finite value).  One workgroup = 64 tokens of one (sequence, head):
 // 16-byte reads along d, a 64 x 64 transpose through LDS, 16-byte writes along the positions.
@@ -488,8 +781,14 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
             scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift};
     static const char* abl = getenv("PRAM_ATTN_ABLATE");
+    static const char* v1 = getenv("PRAM_ATTN_V1");
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    if (!(v1 && v1[0] == '1') && !abl) {
+        if (n_max < 1024) hipLaunchKernelGGL((attention_x3_pipe_kernel<true>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((attention_x3_pipe_kernel<false>), grid, blk, 0, st, p);
+        return pram_launch_status("pram_attention_x3_f32");
+    }
     if (n_max < 1024) {
         hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
