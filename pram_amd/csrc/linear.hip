@@ -44,7 +44,7 @@ __device__ __forceinline__ bool tile_has_rows(const int* __restrict__ lens, int 
 // Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
 template <int MI, int WN>
 __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[MI][2], float* out, int row0, int col0,
-                                                int BM, int BN) {
+                                                int BM, int BN, _Float16* stage = nullptr) {
     using gemm::acc_row;
     const int tid = threadIdx.x;
     const int mlast = p.m - 1, nlast = p.n - 1;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
     // sequences that are not part of this call — AdaGML commits the matching descriptors of the pairs stopping at a layer)
     const bool ragged = p.lens != nullptr;
     const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n) && !ragged;
-#pragma unroll
+#pragma clang loop unroll(full)      // acc[mi] must stay in registers: a rolled loop would index it dynamically (scratch)
     for (int mi = 0; mi < MI; ++mi) {
         const int rbase = row0 + wm * 32 * MI;
         float rc_[16], rs_[16], q0[16], q1[16];
@@ -96,7 +96,41 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             q0[e] = v0;
             q1[e] = v1;
         }
-        if (p.out16 && p.out16_lo) {      // split planes: hi = fp16(v s), lo = fp16(v s - hi)
+        if (p.out16 && p.out16_lo && stage) {
+            // split planes through LDS: a lane owns single columns of 16 rows, so direct stores are 2-byte scatters (128 bytes per
+            // instruction: 256 instructions per thread of a 256 x 256 tile); each wave transposes its 32 x 64 block of both planes
+            // in its own 9 KB of the (now idle) staging memory and writes whole rows, 16 bytes per lane
+            typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+            constexpr int LD = 72;                                  // halves per staged row: 144 B, the two lane halves land 16 banks apart
+            _Float16* sh = stage + wave * (2 * 32 * LD);
+            _Float16* sl = sh + 32 * LD;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = acc_row(0, e, h);
+                const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
+                const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+                sh[rr * LD + r] = h0;
+                sh[rr * LD + 32 + r] = h1;
+                sl[rr * LD + r] = (_Float16)(s0 - (float)h0);
+                sl[rr * LD + 32 + r] = (_Float16)(s1 - (float)h1);
+            }
+            _Float16* oh = reinterpret_cast<_Float16*>(p.out16);
+            _Float16* ol = reinterpret_cast<_Float16*>(p.out16_lo);
+            const int seg = lane & 7;
+            const bool cok = cbase + seg * 8 < p.n;                 // n % 8 == 0 on this path
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = (lane >> 3) + 8 * j;
+                const int row = rbase + mi * 32 + rr;
+                const half8v vh = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
+                const half8v vl = *reinterpret_cast<const half8v*>(sl + rr * LD + seg * 8);
+                if (row < p.m && cok) {
+                    *reinterpret_cast<half8v*>(oh + (size_t)row * p.ldo16 + cbase + seg * 8) = vh;
+                    *reinterpret_cast<half8v*>(ol + (size_t)row * p.ldo16 + cbase + seg * 8) = vl;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one 32-row block at a time: hoisting the next block's work up here spills
+        } else if (p.out16 && p.out16_lo) {      // split planes: hi = fp16(v s), lo = fp16(v s - hi)
             _Float16* oh = reinterpret_cast<_Float16*>(p.out16);
             _Float16* ol = reinterpret_cast<_Float16*>(p.out16_lo);
 #pragma unroll
@@ -406,7 +440,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
-    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
+    // the staging memory is idle now (the main loop ends on a barrier): the plane epilogue transposes through it
+    _Float16* stage = (p.out16_lo && p.n % 8 == 0 && p.ldo16 % 8 == 0) ? reinterpret_cast<_Float16*>(smem_raw) : nullptr;
+    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN, stage);
     if constexpr ((ABL & 4) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) atomicAdd(&gemmx3w::prof[6], (unsigned long long)__builtin_readcyclecounter() - te0);
