@@ -176,11 +176,12 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
     }
     const int nlast = p.cout - 1;
-    int cky = 0, ckx = 0, cci = 0;
+    // taps innermost, like conv_x3_kernel below (L2 re-use of the input window); koff = the chunk's offset in a weight row
+    int cky = 0, ckx = 0, cci = 0, koff = 0;
     auto adv = [&](int kt) {
-        if (kt == 0) { cky = ckx = cci = 0; return; }
-        cci += BK;
-        if (cci >= p.cin) { cci = 0; if (++ckx == p.ks) { ckx = 0; ++cky; } }
+        if (kt == 0) { cky = ckx = cci = koff = 0; return; }
+        if (++ckx == p.ks) { ckx = 0; if (++cky == p.ks) { cky = 0; cci += BK; } }
+        koff = (cky * p.ks + ckx) * p.cin + cci;
     };
     const _Float16* brow16[C::PB];
 #pragma unroll
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
         const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
         return ok[pp] && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
     };
-    auto lb = [&](int pp, int kt) -> uint4 { return *reinterpret_cast<const uint4*>(brow16[pp] + kt * BK); };
+    auto lb = [&](int pp, int kt) -> uint4 { return *reinterpret_cast<const uint4*>(brow16[pp] + koff); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 32 * pp) < p.cout; };
     f32x16 acc[MI][2];
     mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, acc);
