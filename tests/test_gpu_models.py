@@ -343,7 +343,7 @@ def test_sfd2_small_batch_vs_oracle(dev, golden):
         kp = r["keypoints"][b].cpu().numpy().astype(np.int16)
         same = {tuple(x) for x in kp} & {tuple(x) for x in g[f"kp{b}"]}
         print(f"sfd2 small frame {b}: {len(same)}/{len(g[f'kp{b}'])} keypoints identical to the reference (chained)")
-        assert len(same) >= 0.95 * len(g[f"kp{b}"])
+        assert len(same) >= len(g[f"kp{b}"]) - 1      # measured 64 / 64 on both accurate paths; one score tie of margin
         assert tuple(r["descriptors"][b].shape) == (128, len(kp))
 
 
@@ -362,7 +362,7 @@ def test_sfd2_full_frame_golden(dev, golden):
     want = {tuple(x) for x in g["keypoints"]}
     same = sum(tuple(x) in want for x in kp)
     print(f"sfd2 frame0: {same}/2048 keypoints identical to the reference (chained, conv sums differ at 1e-7)")
-    assert same >= 2000
+    assert same >= 2040      # measured 2048 / 2048 on both accurate paths (x3 and f32); 0.4 % margin for score ties at 1e-7
     # stage-isolated: feed the reference keypoints, compare descriptors / seg descriptors
     kref = torch.from_numpy(g["keypoints"].astype(np.float32)).to(dev)
     sc, seg = net.sample(r["score_map"], r["mid_features"], kref, norm_desc=False)
