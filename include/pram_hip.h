@@ -122,6 +122,13 @@ int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* 
                       long long stride_b, float* c, int ldc, long long stride_c, int batch,
                       int m_max, int n_max, int k, float alpha, void* stream);
 
+/* pram_bgemm_nt_f32 on the split-fp16 path: both operands as split planes (value * 16 = hi + lo, what the projection epilogues
+ * write: pram_linear_x3_f32 out_hi / out_lo): a [m_max][lda], b [n_max][ldb == k] per batch element; strides in halves for the
+ * planes, in floats for c.  k % 32 == 0, lda and the plane strides % 8 == 0.  Three fp16 MFMAs per product, fp32-class result. */
+int pram_bgemm_nt_x3p_f32(const void* a_hi, const void* a_lo, int lda, long long stride_a, const void* b_hi, const void* b_lo,
+                          int ldb, long long stride_b, float* c, int ldc, long long stride_c, int batch, int m_max, int n_max,
+                          int k, float alpha, void* stream);
+
 /* y = GELU(LayerNorm(x)) rowwise, eps 1e-5, exact erf GELU (nn.LayerNorm + nn.GELU,
  * nets/segnetvit.py:92-93,161-162; K11).  In place when y == x.  cols <= 1024, cols % 4 == 0 */
 int pram_layernorm_gelu_f32(const float* x, int ldx, float* y, int ldy, const float* gamma,

@@ -501,6 +501,9 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         kmma(sa, 2, fa);
         kmma(sa, 3, fb);
     }
+    // tile 0's K stage is rewritten (K_2) at the END of the first loop pass, before that pass's barrier: every wave must be done
+    // reading K_0 first
+    if (nkt > 2) __syncthreads();
 
     // tile j (not the last): S_{j+1} = K_{j+1} Q^T interleaved with softmax(S_j), then O += V_j P_j; K_{j+2} and V_{j+1} staged
     auto mid = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2]) {

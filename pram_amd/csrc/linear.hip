@@ -326,6 +326,9 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3p_kernel(LinArgs p, Pl
     using C = Cfg<MI, WN>;
     constexpr int BM = C::BM, BN = C::BN;
     __shared__ Smem<MI, WN> smem;
+    if (const int z = blockIdx.y) {      // batched (pram_bgemm_nt_x3p_f32): per-z strides, in halves for the planes, floats for out
+        a.a0h += z * p.sa; a.a0l += z * p.sa; wh += z * p.sw; wl += z * p.sw; p.out += z * p.so;
+    }
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -373,6 +376,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
     constexpr int BM = C::BM, BN = C::BN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<MI, WM, WN>& smem = *reinterpret_cast<Smem<MI, WM, WN>*>(smem_raw);
+    if constexpr (APLANES) {
+        if (const int z = blockIdx.y) {  // batched (pram_bgemm_nt_x3p_f32): per-z strides, in halves for the planes, floats for out
+            a.a0h += z * p.sa; a.a0l += z * p.sa; wh += z * p.sw; wl += z * p.sw; p.out += z * p.so;
+        }
+    }
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -542,7 +550,7 @@ void launch_linear_x3_t(LinArgs& p, const _Float16* wh, const _Float16* wl, floa
 }
 
 template <int MI, int WM, int WN, bool APLANES>
-void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st, int batch = 1) {
     using C = gemmx3w::Cfg<MI, WM, WN>;
     p.tiles_m = cdiv(p.m, C::BM);
     p.tiles_n = cdiv(p.n, C::BN);
@@ -554,10 +562,10 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
     }
     static const char* abl = getenv("PRAM_GEMM_ABLATE");
     const int ab = abl ? atoi(abl) : 0;
-    if (ab == 0) { hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv); return; }
+    if (ab == 0) { hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, batch), dim3(C::NT), shm, st, p, a, wh, wl, inv); return; }
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, 1), dim3(C::NT), shm, st, p, a, wh, wl, inv);
+        hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, batch), dim3(C::NT), shm, st, p, a, wh, wl, inv);
     };
     if (ab == 8) go(linear_x3w_kernel<MI, WM, WN, APLANES, 0, 0>);       // register staging for both operands (no LDS-DMA)
     else if (ab == 1) go(linear_x3w_kernel<MI, WM, WN, APLANES, 1>);      // no staging after the first chunk
@@ -571,24 +579,24 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
 // wide tiles (gemm_core_x3w.h) for outputs at least 256 columns wide: 256 x 256 when that still gives every CU a workgroup,
 // 128 x 256 otherwise.  PRAM_X3_TILE=narrow|w256|w128 overrides (profiling).
 template <bool APLANES>
-bool launch_linear_x3_wide(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+bool launch_linear_x3_wide(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st, int batch = 1) {
     static const char* force = getenv("PRAM_X3_TILE");
     if (force && force[0] == 'n') return false;
     if (p.n < 256 || (p.k0 + p.k1) % 32 != 0) return false;
-    const long big = (long)cdiv(p.m, 256) * cdiv(p.n, 256);
-    if (!force && (long)cdiv(p.m, 128) * cdiv(p.n, 256) < 192) return false;      // too few wide tiles for 256 CUs: narrow tiles fill the chip better
+    const long big = (long)cdiv(p.m, 256) * cdiv(p.n, 256) * batch;
+    if (!force && (long)cdiv(p.m, 128) * cdiv(p.n, 256) * batch < 192) return false;      // too few wide tiles for 256 CUs: narrow tiles fill the chip better
     const bool use256 = force ? (force[1] == '2') : big >= 224;
-    if (use256) launch_linear_x3w_t<4, 2, 4, APLANES>(p, a, wh, wl, inv, st);
-    else launch_linear_x3w_t<2, 2, 4, APLANES>(p, a, wh, wl, inv, st);
+    if (use256) launch_linear_x3w_t<4, 2, 4, APLANES>(p, a, wh, wl, inv, st, batch);
+    else launch_linear_x3w_t<2, 2, 4, APLANES>(p, a, wh, wl, inv, st, batch);
     return true;
 }
 
 template <int MI, int WN>
-void launch_linear_x3p_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st) {
+void launch_linear_x3p_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Float16* wl, float inv, hipStream_t st, int batch = 1) {
     using C = gemmx3::Cfg<MI, WN>;
     p.tiles_m = cdiv(p.m, C::BM);
     p.tiles_n = cdiv(p.n, C::BN);
-    hipLaunchKernelGGL((linear_x3p_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, a, wh, wl, inv);
+    hipLaunchKernelGGL((linear_x3p_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, batch), dim3(gemmx3::NT), 0, st, p, a, wh, wl, inv);
 }
 
 }  // namespace
@@ -775,6 +783,31 @@ extern "C" int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, co
               nullptr, nullptr, 0, stride_a, stride_b, stride_c, 0, 0};
     launch_linear(p, batch, (hipStream_t)stream);
     return pram_launch_status("pram_bgemm_nt_f32");
+}
+
+/* pram_bgemm_nt_f32 on the split-fp16 path: c[z] = alpha * a[z] b[z]^T with both operands given as split planes (value * 16 =
+   hi + lo, as the projection epilogues write them): a [m][lda], b [n][ldb == k] per batch element, strides in halves (a, b)
+   and floats (c).  k % 32 == 0.  The matcher's score matrix mdesc0 . mdesc1^T (nets/gml.py:253). */
+extern "C" int pram_bgemm_nt_x3p_f32(const void* a_hi, const void* a_lo, int lda, long long stride_a, const void* b_hi, const void* b_lo,
+                                     int ldb, long long stride_b, float* c, int ldc, long long stride_c, int batch, int m_max, int n_max,
+                                     int k, float alpha, void* stream) {
+    PRAM_REQUIRE(a_hi && a_lo && b_hi && b_lo && c, "pram_bgemm_nt_x3p_f32: null pointer");
+    PRAM_REQUIRE(k > 0 && k % 32 == 0 && lda % 8 == 0 && ldb == k && stride_a % 8 == 0 && stride_b % 8 == 0,
+                 "pram_bgemm_nt_x3p_f32: need k %% 32 == 0, lda %% 8 == 0, ldb == k, plane strides %% 8 == 0");
+    if (batch == 0 || m_max == 0 || n_max == 0) return PRAM_OK;
+    LinArgs p{nullptr, lda, k, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, c, ldc, m_max, n_max, alpha, 0,
+              nullptr, nullptr, 0, stride_a, stride_b, stride_c, 0, 0, nullptr, 0, nullptr, gemmx3::ACT_SCALE};
+    PlaneArgs a{(const _Float16*)a_hi, (const _Float16*)a_lo, lda, nullptr, nullptr, 0};
+    const _Float16* wh = (const _Float16*)b_hi;
+    const _Float16* wl = (const _Float16*)b_lo;
+    const float inv = 1.0f / (gemmx3::ACT_SCALE * gemmx3::ACT_SCALE);
+    hipStream_t st = (hipStream_t)stream;
+    if (launch_linear_x3_wide<true>(p, a, wh, wl, inv, st, batch)) return pram_launch_status("pram_bgemm_nt_x3p_f32");
+    int mi, wn;
+    gemm::choose_tile(m_max, n_max, &mi, &wn);
+    if (wn == 2) { if (mi == 2) launch_linear_x3p_t<2, 2>(p, a, wh, wl, inv, st, batch); else launch_linear_x3p_t<1, 2>(p, a, wh, wl, inv, st, batch); }
+    else         { if (mi == 2) launch_linear_x3p_t<2, 1>(p, a, wh, wl, inv, st, batch); else launch_linear_x3p_t<1, 1>(p, a, wh, wl, inv, st, batch); }
+    return pram_launch_status("pram_bgemm_nt_x3p_f32");
 }
 
 static int layernorm_gelu_impl(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int rows, int cols,

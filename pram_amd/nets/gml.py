@@ -146,9 +146,14 @@ class GML(blk.PackedCache, nn.Module):
             x = blk.self_block(x, P["self"][i], cos, sin, 2 * B, T, lens)
             x = blk.cross_block(x, P["cross"][i], B, T, lens)
         d = x.shape[-1]
-        md = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25).view(2 * B, T, d)
         ldc = (T + 3) // 4 * 4
-        dist = ops.bgemm_nt(md[:B], md[B:], ldc=ldc)
+        if blk._split_path() and d % 32 == 0:
+            # the matching descriptors leave the projection as split planes and meet on the fp16 matrix pipe as well
+            _, pl = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, split_out="only")
+            dist = ops.bgemm_nt_planes((pl[0][:B * T], pl[1][:B * T]), (pl[0][B * T:], pl[1][B * T:]), B, T, T, ldc=ldc)
+        else:
+            md = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25).view(2 * B, T, d)
+            dist = ops.bgemm_nt(md[:B], md[B:], ldc=ldc)
         r = ops.sinkhorn_match(dist, P["bin"], self.sinkhorn_iterations, p,
                                m_lens=None if lens is None else lens[:B], n_lens=None if lens is None else lens[B:],
                                dual_softmax=not self.with_sinkhorn, n_valid=T)

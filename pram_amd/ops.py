@@ -164,6 +164,24 @@ def bgemm_nt(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, ldc: Optional
     return c
 
 
+def bgemm_nt_planes(a, b, batch: int, m: int, n: int, alpha: float = 1.0, ldc: Optional[int] = None) -> torch.Tensor:
+    """bgemm_nt on the split-fp16 path: a / b are (hi, lo) pairs of fp16 2-D views [batch * m, K] / [batch * n, K] (value * 16 =
+    hi + lo, e.g. row ranges of linear(split_out=...)'s planes) -> c [batch, m, ldc] fp32."""
+    L = _lib.load()
+    for pair in (a, b):
+        for t in pair:
+            assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
+        assert pair[0].stride(0) == pair[1].stride(0)
+    K = a[0].shape[1]
+    assert b[0].shape[1] == K and b[0].stride(0) == K and a[0].shape[0] == batch * m and b[0].shape[0] == batch * n
+    ldc = ldc or n
+    c = torch.empty(batch, m, ldc, device=a[0].device, dtype=torch.float32)
+    lda = a[0].stride(0)
+    _lib.check(L.pram_bgemm_nt_x3p_f32(_p(a[0]), _p(a[1]), lda, m * lda, _p(b[0]), _p(b[1]), K, n * K, _p(c), ldc, m * ldc, batch, m, n, K,
+                                       float(alpha), _st()), "pram_bgemm_nt_x3p_f32")
+    return c
+
+
 def layernorm_gelu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
                     lens: Optional[torch.Tensor] = None, t_pad: int = 0) -> torch.Tensor:
     L = _lib.load()

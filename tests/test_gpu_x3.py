@@ -237,6 +237,21 @@ def test_attention_colmean_x3_cross_equals_two_directions(dev):
     assert torch.equal(both[B:], c1) and torch.equal(both[:B], c0)
 
 
+@pytest.mark.parametrize("B,M,N", [(3, 2048, 2048), (2, 300, 517), (1, 64, 64)])
+def test_bgemm_planes_is_fp32_class(dev, B, M, N):
+    """The matcher's score matrix mdesc0 . mdesc1^T with both operands as split planes (batched launch, wide and narrow tiles)."""
+    from pram_amd import ops
+    a = rnd(31, "bg/a", (B * M, 256), 0.5)
+    b = rnd(31, "bg/b", (B * N, 256), 0.5)
+    ref = torch.einsum("bmk,bnk->bmn", a.view(B, M, 256).double(), b.view(B, N, 256).double()) * 0.25
+    ldc = (N + 3) // 4 * 4
+    got = ops.bgemm_nt_planes(_planes(ops, a.to(dev)), _planes(ops, b.to(dev)), B, M, N, alpha=0.25, ldc=ldc)[:, :, :N]
+    c32 = ops.bgemm_nt(a.view(B, M, 256).to(dev), b.view(B, N, 256).to(dev), alpha=0.25, ldc=ldc)[:, :, :N]
+    ex3, e32 = err(got, ref), err(c32, ref)
+    print(f"bgemm {B}x{M}x{N}: |err| f32 {e32:.2e}  x3 {ex3:.2e}")
+    assert ex3 < 4e-6 and ex3 < 4 * e32 + 1e-6
+
+
 def test_conv_x3_is_fp32_class(dev):
     from pram_amd import ops
     from pram_amd.nets.sfd2 import ResNet4x
