@@ -412,7 +412,7 @@ def main():
     # the split path (three fp16 MFMAs per fp32-class product); the f16 MFMA peak on the single-product C5 path
     kern, peak, mult = {
         "f32": ("attention_kernel (v_mfma_f32_32x32x2_f32 flash attention)", PEAK_F32_MFMA_TFLOPS, 1),
-        "x3": ("attention_x3_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product)", PEAK_F16_MFMA_TFLOPS / 3.0, 3),
+        "x3": ("attention_x3_pipe_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product)", PEAK_F16_MFMA_TFLOPS / 3.0, 3),
         "f16": ("attention_h16_kernel (C5 fp16 MFMA path)", PEAK_F16_MFMA_TFLOPS, 1),
     }[precision]
     roofline = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -44,7 +44,7 @@ with open(os.path.join(root, "profiles", f"{tag}_pmc_summary.md"), "w") as o:
                 f"{2 * r['fetch_kb'] / 1024:.1f} | {r['write_kb']:.0f} | {(2 * r['fetch_kb'] + r['write_kb']) * 1024 / (r['avg_us'] * 1e3):.0f} | {r['lds']:.2f} | {r['wait']:.2f} |\n")
 # bench.py reads roofline.traffic from profiles/pmc_attention.json, keyed by the precision of the run (argv[3], default x3)
 prec = sys.argv[3] if len(sys.argv) > 3 else "x3"
-name = {"f32": "attention_kernel", "x3": "attention_x3_kernel", "f16": "attention_h16_kernel"}[prec]
+name = {"f32": "attention_kernel", "x3": "attention_x3_pipe_kernel", "f16": "attention_h16_kernel"}[prec]
 att = next((r for r in rows if r["kernel"].startswith(name)), None)
 if att:
     path = os.path.join(root, "profiles", "pmc_attention.json")
