@@ -16,6 +16,15 @@
  *     element has the padded max length).  The reference has no masks; a padded row/key is
  *     never read into a softmax, so each element computes exactly its B=1 result.
  *   - token matrices are row-major [rows][ld]; heads are 64-wide column blocks.
+ *
+ * Limits (each is checked and comes back as PRAM_E_ARG with a message, never as a wrong result):
+ *   - attention heads are exactly 64 wide (the shipped models: hidden 256 = 4 heads; pram_amd's Python layer raises on any
+ *     other hidden_dim before it gets here);
+ *   - keypoint selection keeps at most 8192 keypoints per frame when max_keypoints is positive (the top-k is sorted in LDS),
+ *     or all of them (max_keypoints >= h * w);
+ *   - AdaGML pruning handles token sets of at most 8192 tokens (pram_adagml_prune_f32);
+ *   - LayerNorm rows are at most 1024 wide; the split-fp16 GEMMs need K % 32 == 0 (other shapes: the exact-fp32 entry);
+ *   - the split-fp16 operands carry value * 16 in fp16: |x| must stay below 4094 (activations of the three networks are O(10)).
  */
 #ifndef PRAM_HIP_H
 #define PRAM_HIP_H
