@@ -205,10 +205,19 @@ int pram_attention_x3_colmean_f32(const void* q_hi, const void* q_lo, int ldq, c
                                   const float* lse2, float* colmean, const int* q_lens, const int* k_lens, int batch,
                                   int heads, int m_max, int n_max, float scale, int kv_shift, void* stream);
 
+/* Single-product ("fp16 MFMA path", BASELINE C5) flash attention on the software-pipelined kernel of the split path: q / k = fp16
+ * row-major [rows][ld] (pram_linear_f16_h16), vt16 = the transposed, key-permuted fp16 values [batch][heads][64][tv] written by
+ * pram_attention_x3_vt with NULL lo planes.  One fp16 MFMA per product; the probabilities are rounded to fp16 like the inputs
+ * (this path's own, looser tolerance).  Output fp32; lse2 / lens / kv_shift as pram_attention_x3_f32. */
+int pram_attention_h16t_f32(const void* q16, int ldq, const void* k16, int ldk, const void* vt16, float* out, int ldo,
+                            float* lse2, const int* q_lens, const int* k_lens, int batch, int heads, int m_max,
+                            int n_max, float scale, int kv_shift, void* stream);
+
 /* Row-major value planes [seqs * t_max][ldv] (head h at columns 64 h ..) -> the transposed, key-permuted planes
  * pram_attention_x3_f32 stages with plain 16-byte copies: [seqs][heads][64][tv], tv = t_max rounded up to 64, position of
  * token t = 64 (t / 64) + perm(t % 64) (the order in which the S^T accumulator registers hold the keys); tokens
- * t >= lens[seq] (NULL: t_max) are written as zeros. */
+ * t >= lens[seq] (NULL: t_max) are written as zeros.  v_lo == vt_lo == NULL: one plane only (the fp16 values of
+ * pram_attention_h16t_f32). */
 int pram_attention_x3_vt(const void* v_hi, const void* v_lo, int ldv, void* vt_hi, void* vt_lo, const int* lens,
                          int seqs, int heads, int t_max, void* stream);
 

@@ -38,6 +38,7 @@ struct ArgsX {
     float scale2;                    // scale * log2(e) / IN_SCALE^2
     int q_tiles;
     int kv_shift;                    // as in attention.hip
+    float in_scale;                  // scale of the planes in the single-product mode (1: plain fp16 q / k / v)
 };
 
 struct alignas(16) Smem {
@@ -46,6 +47,13 @@ struct alignas(16) Smem {
     _Float16 vth[2][D * BKV];   // [d][pos(key)], slot-swizzled
     _Float16 vtl[2][D * BKV];
 };  // 64 KiB -> two workgroups per CU
+
+struct alignas(16) SmemHi {     // single-product mode: hi planes only
+    _Float16 kh[2][BKV * D];
+    _Float16 vth[2][D * BKV];
+};
+template <bool HI> struct SmemSel { typedef Smem type; };
+template <> struct SmemSel<true> { typedef SmemHi type; };
 
 __device__ __forceinline__ int key_of(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 // position of key (0..63) inside a V^T row: inverse of key = 32t + (i&3) + 16u + 8(i>>2) + 4h
@@ -293,9 +301,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
 // wave keeps both pipes busy on its own.  Costs: a second 32-register score tile, and K staged one tile ahead of V (K_{j+2} and
 // V_{j+1} land while K_{j+1} and V_j are read: same 64 KB of LDS).  The arithmetic — and every bit of the result — is that of
 // the kernel above; the soft-max is written with packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32).
-template <bool PSPLIT>
+// HI: single-product mode (BASELINE C5's fp16 path): only the hi planes exist (q / k / v rounded to fp16, scale p.in_scale = 1),
+// one MFMA per product; half the LDS, so the co-residency is bounded by registers only.
+template <bool PSPLIT, bool HI = false>
 __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
-    __shared__ Smem s;
+    static_assert(!(HI && PSPLIT), "the single-product mode carries one plane of everything");
+    __shared__ typename SmemSel<HI>::type s;
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const int nblk = p.batch * p.heads * p.q_tiles;
@@ -332,10 +343,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         qh[c] = *reinterpret_cast<const half8*>(p.qh + qoff + c * 16 + h * 8);
-        ql[c] = *reinterpret_cast<const half8*>(p.ql + qoff + c * 16 + h * 8);
+        if constexpr (!HI) ql[c] = *reinterpret_cast<const half8*>(p.ql + qoff + c * 16 + h * 8);
         if (!q_ok)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { qh[c][i] = (_Float16)0.f; ql[c][i] = (_Float16)0.f; }
+            for (int i = 0; i < 8; ++i) { qh[c][i] = (_Float16)0.f; if constexpr (!HI) ql[c][i] = (_Float16)0.f; }
     }
 
     const int lrow = tid >> 3, lseg = tid & 7;
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         for (int pp = 0; pp < 2; ++pp) {
             const size_t kc = (size_t)min(kt * BKV + lrow + 32 * pp, klen - 1);
             krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
-            krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
+            if constexpr (!HI) krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
         }
     };
     auto gload_v = [&](int kt) {
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         for (int pp = 0; pp < 2; ++pp) {
             const size_t vo = voff + (size_t)(lrow + 32 * pp) * p.tv + kt * BKV + lseg * 8;
             vrh[pp] = *reinterpret_cast<const half8*>(p.vh + vo);
-            vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
+            if constexpr (!HI) vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
         }
     };
     auto lstore_k = [&](int buf) {
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
             const int row = lrow + 32 * pp;
             const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
             *reinterpret_cast<half8*>(&s.kh[buf][off]) = krh[pp];
-            *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
+            if constexpr (!HI) *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
         }
     };
     auto lstore_v = [&](int buf) {
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
             const int row = lrow + 32 * pp;
             const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
             *reinterpret_cast<half8*>(&s.vth[buf][off]) = vrh[pp];
-            *reinterpret_cast<half8*>(&s.vtl[buf][off]) = vrl[pp];
+            if constexpr (!HI) *reinterpret_cast<half8*>(&s.vtl[buf][off]) = vrl[pp];
         }
     };
 
@@ -380,14 +391,18 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;
         f.h0 = *reinterpret_cast<const half8*>(&s.kh[buf][r * D + slot]);
         f.h1 = *reinterpret_cast<const half8*>(&s.kh[buf][(32 + r) * D + slot]);
-        f.l0 = *reinterpret_cast<const half8*>(&s.kl[buf][r * D + slot]);
-        f.l1 = *reinterpret_cast<const half8*>(&s.kl[buf][(32 + r) * D + slot]);
+        if constexpr (!HI) {
+            f.l0 = *reinterpret_cast<const half8*>(&s.kl[buf][r * D + slot]);
+            f.l1 = *reinterpret_cast<const half8*>(&s.kl[buf][(32 + r) * D + slot]);
+        }
     };
     auto kmma = [&](f32x16 (&st)[2], int c, const KFrag& f) {
-        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, qh[c], st[0], 0, 0, 0);
-        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, qh[c], st[1], 0, 0, 0);
-        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ql[c], st[0], 0, 0, 0);
-        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ql[c], st[1], 0, 0, 0);
+        if constexpr (!HI) {
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, qh[c], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, qh[c], st[1], 0, 0, 0);
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ql[c], st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ql[c], st[1], 0, 0, 0);
+        }
         st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, qh[c], st[0], 0, 0, 0);
         st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, qh[c], st[1], 0, 0, 0);
     };
@@ -396,8 +411,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
         f.h0 = *reinterpret_cast<const half8*>(&s.vth[buf][r * BKV + slot]);
         f.h1 = *reinterpret_cast<const half8*>(&s.vth[buf][(32 + r) * BKV + slot]);
-        f.l0 = *reinterpret_cast<const half8*>(&s.vtl[buf][r * BKV + slot]);
-        f.l1 = *reinterpret_cast<const half8*>(&s.vtl[buf][(32 + r) * BKV + slot]);
+        if constexpr (!HI) {
+            f.l0 = *reinterpret_cast<const half8*>(&s.vtl[buf][r * BKV + slot]);
+            f.l1 = *reinterpret_cast<const half8*>(&s.vtl[buf][(32 + r) * BKV + slot]);
+        }
     };
 
     const int nkt = (klen + BKV - 1) / BKV;
@@ -451,8 +468,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
             }
     };
     auto vmma = [&](int t, int u, const VFrag& f) {
-        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
+        if constexpr (!HI) {
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
+        }
         if constexpr (PSPLIT) {
             oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
             oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
@@ -527,10 +546,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
             softmax(sc);
             // one MFMA, then VALU work of the soft-max in its shadow; the eight fragment reads go out with the first groups
 #pragma unroll
-            for (int g = 0; g < 24; ++g) {
+            for (int g = 0; g < (HI ? 8 : 24); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if (g < (HI ? 4 : 8)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, HI ? 18 : 6, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             pv(vbuf);
@@ -564,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     if (in_a) last(sa); else last(sb);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (1.0f / IN_SCALE) / l_tot;
+    const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_tot;
     if (q_ok) {
         float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
 #pragma unroll
@@ -600,12 +619,15 @@ __global__ __launch_bounds__(256) void vt_kernel(VtArgs p) {
     half8 a0, a1, b0, b1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a0[i] = (_Float16)0.f; a1[i] = a0[i]; b0[i] = a0[i]; b1[i] = a0[i]; }
+    const bool two = p.vl != nullptr;                        // single-product mode: one plane
     if (t < len) {
         const size_t src = ((size_t)seq * p.t_max + t) * p.ldv + head * D + seg * 16;
         a0 = *reinterpret_cast<const half8*>(p.vh + src);
         a1 = *reinterpret_cast<const half8*>(p.vh + src + 8);
-        b0 = *reinterpret_cast<const half8*>(p.vl + src);
-        b1 = *reinterpret_cast<const half8*>(p.vl + src + 8);
+        if (two) {
+            b0 = *reinterpret_cast<const half8*>(p.vl + src);
+            b1 = *reinterpret_cast<const half8*>(p.vl + src + 8);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -619,8 +641,10 @@ __global__ __launch_bounds__(256) void vt_kernel(VtArgs p) {
     const size_t dst = (((size_t)seq * p.heads + head) * D + d) * p.tv + blk * 64 + part * 16;
     *reinterpret_cast<half8*>(p.oh + dst) = *reinterpret_cast<const half8*>(&sh[0][d][part * 16]);
     *reinterpret_cast<half8*>(p.oh + dst + 8) = *reinterpret_cast<const half8*>(&sh[0][d][part * 16 + 8]);
-    *reinterpret_cast<half8*>(p.ol + dst) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16]);
-    *reinterpret_cast<half8*>(p.ol + dst + 8) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16 + 8]);
+    if (two) {
+        *reinterpret_cast<half8*>(p.ol + dst) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16]);
+        *reinterpret_cast<half8*>(p.ol + dst + 8) = *reinterpret_cast<const half8*>(&sh[1][d][part * 16 + 8]);
+    }
 }
 
 // ---------------------------------------------------------------- column means of the attention matrix (AdaGML)
@@ -758,7 +782,7 @@ extern "C" int pram_attention_x3_colmean_f32(const void* q_hi, const void* q_lo,
    planes [seqs][heads][64][tv], tv = t_max rounded up to a multiple of 64; tokens t >= lens[seq] (NULL = t_max) become zeros. */
 extern "C" int pram_attention_x3_vt(const void* v_hi, const void* v_lo, int ldv, void* vt_hi, void* vt_lo, const int* lens,
                                     int seqs, int heads, int t_max, void* stream) {
-    PRAM_REQUIRE(v_hi && v_lo && vt_hi && vt_lo, "pram_attention_x3_vt: null pointer");
+    PRAM_REQUIRE(v_hi && vt_hi && ((v_lo == nullptr) == (vt_lo == nullptr)), "pram_attention_x3_vt: null pointer (the lo planes go together)");
     PRAM_REQUIRE(ldv % 8 == 0 && heads > 0 && seqs >= 0 && t_max >= 0, "pram_attention_x3_vt: bad sizes");
     if (seqs == 0 || t_max == 0) return PRAM_OK;
     const int tv = cdiv(t_max, 64) * 64;
@@ -782,7 +806,7 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     PRAM_REQUIRE(n_max > 0, "pram_attention_x3_f32: empty key set");
     ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
-            scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift};
+            scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift, IN_SCALE};
     static const char* abl = getenv("PRAM_ATTN_ABLATE");
     static const char* v1 = getenv("PRAM_ATTN_V1");
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
@@ -805,4 +829,22 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
         default: hipLaunchKernelGGL((attention_x3_kernel<0, false>), grid, blk, 0, st, p);
     }
     return pram_launch_status("pram_attention_x3_f32");
+}
+
+/* Single-product ("fp16 MFMA path", BASELINE C5) flash attention on the pipelined kernel: q / k = fp16 row-major [rows][ld]
+   (what pram_linear_f16_h16 writes), vt = the transposed, key-permuted fp16 values of pram_attention_x3_vt called with NULL lo
+   planes.  One fp16 MFMA per product, fp32 accumulation and soft-max; the probabilities are rounded to fp16 (scaled by 2^14)
+   like the inputs.  Output fp32.  Same arguments otherwise as pram_attention_x3_f32. */
+extern "C" int pram_attention_h16t_f32(const void* q16, int ldq, const void* k16, int ldk, const void* vt16, float* out, int ldo,
+                                       float* lse2, const int* q_lens, const int* k_lens, int batch, int heads, int m_max,
+                                       int n_max, float scale, int kv_shift, void* stream) {
+    PRAM_REQUIRE(q16 && k16 && vt16 && out, "pram_attention_h16t_f32: null pointer");
+    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "pram_attention_h16t_f32: ld of the fp16 operands must be a multiple of 8");
+    PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_h16t_f32: bad sizes");
+    if (batch == 0 || m_max == 0) return PRAM_OK;
+    PRAM_REQUIRE(n_max > 0, "pram_attention_h16t_f32: empty key set");
+    ArgsX p{(const _Float16*)q16, nullptr, (const _Float16*)k16, nullptr, (const _Float16*)vt16, nullptr, out, lse2, q_lens, k_lens,
+            ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f};
+    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_h16t_f32");
 }

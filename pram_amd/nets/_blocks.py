@@ -113,7 +113,8 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
     if _half_path() and not want_colmean:
         # fp16 path: the projection writes q | k | v as fp16 only (what the fp16 attention would round them to anyway)
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), half_copy="only")
-        ctx = ops.attention_h16(h16[:, :hid], h16[:, hid:2 * hid], h16[:, 2 * hid:], S, HEADS, T, T, scale, lens, lens)
+        vt = ops.value_t16(h16[:, 2 * hid:], S, HEADS, T, lens)
+        ctx = ops.attention_h16t(h16[:, :hid], h16[:, hid:2 * hid], vt, S, HEADS, T, T, scale, lens, lens)
         return _mlp_tail(x, ctx, p)
     qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), lens=lens, t_pad=T)
     q, k, v = qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:]
@@ -143,7 +144,8 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     if _half_path() and not want_colmean:
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], half_copy="only")
         qk16, v16 = h16[:, :hid], h16[:, hid:]
-        ctx = ops.attention_h16(qk16, qk16, v16, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
+        vt = ops.value_t16(v16, 2 * B, HEADS, T, lens)
+        ctx = ops.attention_h16t(qk16, qk16, vt, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
         return _mlp_tail(x, ctx, p)
     qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], lens=lens, t_pad=T)          # [2B*T, 512] = [qk | v]
     qk, v = qkv[:, :hid], qkv[:, hid:]

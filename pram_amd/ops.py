@@ -376,6 +376,42 @@ def attention_h16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int,
     return (out, lse) if want_lse else out
 
 
+def value_t16(v16: torch.Tensor, seqs: int, heads: int, t_max: int, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 row-major values [seqs * t_max, >= heads * 64] -> the transposed, key-permuted fp16 values [seqs, heads, 64, tv] of
+    attention_h16t (the single-plane form of value_planes_t)."""
+    L = _lib.load()
+    assert v16.is_cuda and v16.dtype == torch.float16 and v16.dim() == 2 and v16.stride(1) == 1
+    tv = (t_max + 63) // 64 * 64
+    out = torch.empty(seqs, heads, 64, tv, device=v16.device, dtype=torch.float16)
+    _lib.check(L.pram_attention_x3_vt(_p(v16), None, v16.stride(0), _p(out), None, _p(lens), seqs, heads, t_max, _st()), "pram_attention_x3_vt")
+    return out
+
+
+def attention_h16t(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int, scale: float,
+                   q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None, want_lse: bool = False,
+                   out: Optional[torch.Tensor] = None, kv_shift: int = 0):
+    """The fp16 path's attention on the software-pipelined kernel: fp16 q / k (2-D views), vt = value_t16(...) of the key side.
+    One fp16 MFMA per product, probabilities rounded to fp16 (tolerance of the fp16 path)."""
+    L = _lib.load()
+    for t in (q, k):
+        assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
+    assert vt.is_contiguous() and vt.dtype == torch.float16
+    if out is None:
+        out = torch.empty(batch * m_max, heads * 64, device=q.device, dtype=torch.float32)
+    lse = torch.empty(batch, heads, m_max, device=q.device, dtype=torch.float32) if want_lse else None
+    probe = attention_probe
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(L.pram_attention_h16t_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), _p(out), out.stride(0), _p(lse), _p(q_lens),
+                                         _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_h16t_f32")
+    if probe is not None:
+        e1.record()
+        kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
+        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1))
+    return (out, lse) if want_lse else out
+
+
 def value_planes_t(v, seqs: int, heads: int, t_max: int, lens: Optional[torch.Tensor] = None):
     """(hi, lo) row-major value planes [seqs * t_max, >= heads * 64] (column slices of linear(split_out=...)'s planes) ->
     the transposed, key-permuted planes [seqs, heads, 64, tv] attention_x3 stages with 16-byte copies; zeros beyond lens."""

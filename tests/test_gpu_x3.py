@@ -252,6 +252,35 @@ def test_bgemm_planes_is_fp32_class(dev, B, M, N):
     assert ex3 < 4e-6 and ex3 < 4 * e32 + 1e-6
 
 
+@pytest.mark.parametrize("B,M,N,ragged", [(2, 2048, 2048, False), (3, 300, 517, True), (1, 64, 64, False)])
+def test_attention_h16t_single_product_mode(dev, B, M, N, ragged):
+    """The fp16 path's attention on the pipelined kernel (hi planes only, one MFMA per product): against fp64 fed the same
+    fp16-rounded q / k / v the error is that of fp16 probabilities (2^-12 relative each), far inside the fp16 path's own bar;
+    ragged lengths, cross-attention shift and lse like the split-path kernel."""
+    from pram_amd import ops
+    Hh = 4
+    q = rnd(25, "h16/q", (B, M, Hh * 64), 1.2).half()
+    k = rnd(25, "h16/k", (B, N, Hh * 64), 1.2).half()
+    v = rnd(25, "h16/v", (B, N, Hh * 64)).half()
+    qlens = [M - 37 * i for i in range(B)] if ragged else None
+    klens = [N - 61 * i for i in range(B)] if ragged else None
+    sp = lambda t, L: t.float().view(B, L, Hh, 64).permute(0, 2, 1, 3)
+    ref = _attn_ref(sp(q, M), sp(k, N), sp(v, N), 0.125, qlens, klens).permute(0, 2, 1, 3).reshape(B, M, Hh * 64)
+    qd, kd, vd = q.view(B * M, -1).to(dev), k.view(B * N, -1).to(dev), v.view(B * N, -1).to(dev)
+    ql = None if qlens is None else torch.tensor(qlens, dtype=torch.int32, device=dev)
+    kl = None if klens is None else torch.tensor(klens, dtype=torch.int32, device=dev)
+    out, lse = ops.attention_h16t(qd, kd, ops.value_t16(vd, B, Hh, N, kl), B, Hh, M, N, 0.125, ql, kl, want_lse=True)
+    old = ops.attention_h16(qd, kd, vd, B, Hh, M, N, 0.125, ql, kl).view(B, M, -1)
+    out = out.view(B, M, -1)
+    e_new = e_old = 0.0
+    for b in range(B):
+        mq = M if qlens is None else qlens[b]
+        e_new = max(e_new, err(out[b, :mq], ref[b, :mq]))
+        e_old = max(e_old, err(old[b, :mq], ref[b, :mq]))
+    print(f"attention_h16t B{B} {M}x{N}: |err| vs fp64 (same fp16 operands) {e_new:.2e}; attention_h16 {e_old:.2e}")
+    assert torch.isfinite(lse).all() and e_new < 5e-4
+
+
 def test_conv_x3_is_fp32_class(dev):
     from pram_amd import ops
     from pram_amd.nets.sfd2 import ResNet4x
