@@ -124,7 +124,9 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                 const int row = rbase + mi * 32 + rr;
                 const half8v vh = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
                 const half8v vl = *reinterpret_cast<const half8v*>(sl + rr * LD + seg * 8);
-                if (row < p.m && cok) {
+                bool ok = row < p.m && cok;
+                if (ragged && ok) { const int sq = row / p.t_pad; ok = row - sq * p.t_pad < p.lens[sq]; }      // as the fp32 output below
+                if (ok) {
                     *reinterpret_cast<half8v*>(oh + (size_t)row * p.ldo16 + cbase + seg * 8) = vh;
                     *reinterpret_cast<half8v*>(ol + (size_t)row * p.ldo16 + cbase + seg * 8) = vl;
                 }
@@ -136,7 +138,9 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + acc_row(mi, e, h);
-                if (row < p.m) {
+                bool ok = row < p.m;
+                if (ragged && ok) { const int sq = row / p.t_pad; ok = row - sq * p.t_pad < p.lens[sq]; }
+                if (ok) {
                     const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
                     const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
                     if (c0ok) { oh[(size_t)row * p.ldo16 + c0] = h0; ol[(size_t)row * p.ldo16 + c0] = (_Float16)(s0 - (float)h0); }

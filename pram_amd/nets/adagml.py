@@ -164,7 +164,9 @@ class AdaGML(GML):
         tiny = torch.zeros(B, device=dev, dtype=torch.bool)        # run(): a still-active pair was pruned to <= 5 tokens
         stop_layer = torch.full((B,), -1, device=dev, dtype=torch.int32)
         d = self.config['hidden_dim']
-        md_final = torch.zeros(2 * B, T, d, device=dev, dtype=torch.float32)
+        planes_md = blk._split_path() and d % 32 == 0       # matching descriptors as split planes: the score matrix runs on the fp16 pipe too
+        md_final = None if planes_md else torch.zeros(2 * B, T, d, device=dev, dtype=torch.float32)
+        md_planes = torch.zeros(2, 2 * B * T, d, device=dev, dtype=torch.float16) if planes_md else None
         lens_final = lens.clone()
         ind_final = ind.clone()
         x = ops.linear(X.view(2 * B * T, -1), P["in_w"], P["in_b"])
@@ -199,13 +201,20 @@ class AdaGML(GML):
                 # GEMM skips every tile of the other pairs (lens 0) and leaves their rows as they are
                 sel = stop_now.repeat(2)
                 lens_stop = torch.where(sel, lens, torch.zeros_like(lens)).contiguous()
-                ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25, out=md_final.view(2 * B * T, d), lens=lens_stop, t_pad=T)
+                if planes_md:
+                    ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25, split_out="only", out_planes=(md_planes[0], md_planes[1]),
+                               lens=lens_stop, t_pad=T)
+                else:
+                    ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25, out=md_final.view(2 * B * T, d), lens=lens_stop, t_pad=T)
                 lens_final = torch.where(sel, lens, lens_final)
                 ind_final = torch.where(sel[:, None], ind, ind_final)
                 stop_layer = torch.where(stop_now, torch.full_like(stop_layer, ni), stop_layer)
                 active = active & ~stop_now
         ldc = (T + 3) // 4 * 4
-        dist = ops.bgemm_nt(md_final[:B].contiguous(), md_final[B:].contiguous(), ldc=ldc)
+        if planes_md:
+            dist = ops.bgemm_nt_planes((md_planes[0][:B * T], md_planes[1][:B * T]), (md_planes[0][B * T:], md_planes[1][B * T:]), B, T, T, ldc=ldc)
+        else:
+            dist = ops.bgemm_nt(md_final[:B].contiguous(), md_final[B:].contiguous(), ldc=ldc)
         lf0, lf1 = lens_final[:B].contiguous(), lens_final[B:].contiguous()
         r = ops.sinkhorn_match(dist, P["bin"], self.sinkhorn_iterations, p, m_lens=lf0, n_lens=lf1,
                                dual_softmax=not self.with_sinkhorn, n_valid=T)

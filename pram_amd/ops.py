@@ -38,7 +38,7 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
            rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, half_copy: str = "no", split_out: str = "no",
-           precision: Optional[str] = None, lens: Optional[torch.Tensor] = None, t_pad: int = 0):
+           precision: Optional[str] = None, lens: Optional[torch.Tensor] = None, t_pad: int = 0, out_planes=None):
     """out = alpha * ([x | x2] @ w.T + bias) + residual.  x [..., k0] (contiguous rows), w [n, k0+k1].
     precision: None = ops.gemm_precision; "f32" exact-fp32 MFMA, "x3" split-fp16 (three fp16 MFMAs per product, fp32-class
     accuracy), "f16" single fp16 product (BASELINE C5).  Shapes a fast path cannot take (K not a multiple of 32 / 64)
@@ -48,7 +48,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     split_out (x3 path only): "also" -> (out fp32, (hi, lo)), "only" -> (None, (hi, lo)): the result * 16 as two fp16 planes,
     the operand format of attention_x3.
     lens / t_pad (f32 and x3 paths): ragged token matrix — rows are sequences of t_pad rows with lens[s] valid ones; output tiles
-    without a valid row are skipped and left untouched."""
+    without a valid row are skipped and left untouched (and only valid rows are stored).
+    out_planes (with split_out): a (hi, lo) pair of existing fp16 buffers to write into instead of fresh ones."""
     L = _lib.load()
     x = x.contiguous()
     m, k0 = _rows2d(x, "x")
@@ -89,7 +90,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if split_out != "no":
         if not usex3:
             raise _lib.PramHipError("linear(split_out=...) needs the split-fp16 GEMM path (precision 'x3', K % 32 == 0)")
-        planes = torch.empty(2, *x.shape[:-1], n, device=x.device, dtype=torch.float16)
+        if out_planes is not None:      # persistent plane buffers (AdaGML commits the rows of the pairs stopping at a layer)
+            planes = out_planes
+            assert planes[0].dtype == torch.float16 and planes[0].is_contiguous() and planes[1].is_contiguous() and planes[0].shape[-1] == n
+        else:
+            planes = torch.empty(2, *x.shape[:-1], n, device=x.device, dtype=torch.float16)
         o32 = out if split_out == "also" else None
         if m:
             wh, wl, ws = split_weight(w)

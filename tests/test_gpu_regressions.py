@@ -192,6 +192,15 @@ def test_ragged_linear_touches_only_valid_rows(dev, prec):
     for s_, n in enumerate(lens.tolist()):
         assert torch.equal(o3[s_, :n], f3[s_, :n])
         assert bool((o3[s_, n:] == -7.0).all())
+    if prec == "x3":
+        # the split-plane output obeys the same rule (AdaGML keeps its matching descriptors in persistent planes)
+        _, ref_pl = ops.linear(x, w, b, precision="x3", split_out="only")
+        keep = torch.full((2, S * T, N), 5.0, device=dev, dtype=torch.float16)
+        ops.linear(x, w, b, precision="x3", split_out="only", out_planes=(keep[0], keep[1]), lens=lens, t_pad=T)
+        for pl_i in (0, 1):
+            k3, r3 = keep[pl_i].view(S, T, N), ref_pl[pl_i].view(S, T, N)
+            for s_, n in enumerate(lens.tolist()):
+                assert torch.equal(k3[s_, :n], r3[s_, :n]) and bool((k3[s_, n:] == 5.0).all())
     h = ops.linear(x, w, b, precision=prec).clone()
     g, bt = torch.ones(N, device=dev), torch.zeros(N, device=dev)
     ref = ops.layernorm_gelu_(h.clone(), g, bt)
