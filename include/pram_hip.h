@@ -101,6 +101,16 @@ int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float* a1, int l
  * out72 = HOST array of 72 counters; reset != 0 clears them after the read. */
 int pram_debug_gemm_phases(unsigned long long* out72, int reset);
 
+/* The q | k | v projection of an attention block in one call (nets/segnetvit.py:87-95, nets/gml.py:151-159), split-fp16 path:
+ * columns [0, vt_col0) leave as row-major split planes [m][ldo16] (out_hi / out_lo: the q / k operands of pram_attention_x3_f32,
+ * rotary applied to the first rot_cols of them when PRAM_LIN_ROTARY is set); the last heads * 64 columns — the values — leave
+ * as the transposed, key-permuted planes [m / t_seq][heads][64][t_seq] that pram_attention_x3_vt would build from them (zeros
+ * for tokens >= lens[s]; lens may be NULL).  Rows are sequences of t_seq tokens, t_seq % 64 == 0; n == vt_col0 + heads * 64. */
+int pram_linear_x3_qkv_f32(const float* a0, int lda0, int k0, const void* w_hi, const void* w_lo, float w_scale,
+                           const float* bias, void* out_hi, void* out_lo, int ldo16, void* vt_hi, void* vt_lo, int vt_col0,
+                           int heads, int t_seq, int m, int n, int flags, const float* rot_cos, const float* rot_sin,
+                           int rot_cols, const int* lens, void* stream);
+
 /* pram_linear_x3_f32 with the activations already split: [A0 | A1] given as fp16 planes (value * 16 = hi + lo, [m][lda]
  * halves) written by the epilogues of pram_linear_x3[p]_f32 / pram_attention_x3_f32 / pram_layernorm_gelu_x3.  Both operands are
  * then staged with plain 16-byte copies (the fp32-input form splits A again in every column tile and is instruction-issue

@@ -31,6 +31,9 @@ struct LinArgs {
     // ragged token matrices: rows are sequences of t_pad rows, sequence s has lens[s] valid ones; output tiles without a valid
     // row are skipped (their outputs are left untouched).  lens == nullptr: every row counts.
     const int* lens; int t_pad;
+    // value columns of a q | k | v projection written TRANSPOSED (the V^T planes of attention_x3.hip, key-permuted) instead of
+    // row-major: columns >= vt_col0 are vt_heads heads of 64 value dims, rows are sequences of vt_t (% 64 == 0) tokens
+    void* vt_hi; void* vt_lo; int vt_col0, vt_heads, vt_t, vt_tv;
 };
 
 __device__ __forceinline__ bool tile_has_rows(const int* __restrict__ lens, int t_pad, int row0, int bm, int m) {
@@ -96,7 +99,43 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             q0[e] = v0;
             q1[e] = v1;
         }
-        if (p.out16 && p.out16_lo && stage) {
+        if (p.vt_hi && cbase >= p.vt_col0) {
+            // Value head of the projection: straight into the V^T planes.  The accumulator layout IS the key permutation of
+            // attention_x3.hip (pos_of_key): registers 8g .. 8g+7 of a lane are eight consecutive positions of one head dim, so a
+            // lane writes 16 bytes per plane, head dim and register half.  Tokens beyond their sequence's length become zeros
+            // (a masked key must meet a finite value).
+            typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+            const int r0 = rbase + mi * 32;
+            if (r0 < p.m) {
+                const int sq = r0 / p.vt_t, t0 = r0 - sq * p.vt_t;
+                const int len = p.lens ? p.lens[sq] : p.vt_t;
+                const int head = (cbase - p.vt_col0) >> 6;
+                const size_t drow = ((size_t)sq * p.vt_heads + head) * 64;
+                const int pos0 = (t0 & ~63) + ((t0 >> 5) & 1) * 32 + h * 8;
+                _Float16* vh = reinterpret_cast<_Float16*>(p.vt_hi);
+                _Float16* vl = reinterpret_cast<_Float16*>(p.vt_lo);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    half8v h0, l0, h1, l1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = 8 * g + i;
+                        const bool ok = t0 + (i & 3) + 8 * (2 * g + (i >> 2)) + 4 * h < len;
+                        const float s0 = ok ? q0[e] * p.out16_scale : 0.f, s1 = ok ? q1[e] * p.out16_scale : 0.f;
+                        h0[i] = (_Float16)s0;
+                        l0[i] = (_Float16)(s0 - (float)h0[i]);
+                        h1[i] = (_Float16)s1;
+                        l1[i] = (_Float16)(s1 - (float)h1[i]);
+                    }
+                    const size_t d0 = (drow + r) * p.vt_tv + pos0 + 16 * g, d1 = (drow + 32 + r) * p.vt_tv + pos0 + 16 * g;
+                    *reinterpret_cast<half8v*>(vh + d0) = h0;
+                    *reinterpret_cast<half8v*>(vl + d0) = l0;
+                    *reinterpret_cast<half8v*>(vh + d1) = h1;
+                    *reinterpret_cast<half8v*>(vl + d1) = l1;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (p.out16 && p.out16_lo && stage) {
             // split planes through LDS: a lane owns single columns of 16 rows, so direct stores are 2-byte scatters (128 bytes per
             // instruction: 256 instructions per thread of a 256 x 256 tile); each wave transposes its 32 x 64 block of both planes
             // in its own 9 KB of the (now idle) staging memory and writes whole rows, 16 bytes per lane
@@ -648,7 +687,9 @@ extern "C" int pram_debug_gemm_phases(unsigned long long* out72, int reset) {
     return PRAM_OK;
 }
 
-static int linear_x3_impl(const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+struct VtOut { void* hi; void* lo; int col0, heads, t_seq; };
+
+static int linear_x3_impl(const VtOut* vt, const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
                                   const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
                                   float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                   int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
@@ -663,6 +704,14 @@ static int linear_x3_impl(const int* lens, int t_pad, const float* a0, int lda0,
     LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
               rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE, lens, t_pad};
     PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_x3_f32: lens needs t_pad > 0");
+    if (vt) {
+        PRAM_REQUIRE(vt->hi && vt->lo && out_hi && out_lo, "pram_linear_x3_qkv_f32: null pointer");
+        PRAM_REQUIRE(vt->t_seq > 0 && vt->t_seq % 64 == 0 && m % vt->t_seq == 0 && (!lens || t_pad == vt->t_seq),
+                     "pram_linear_x3_qkv_f32: sequences must be a multiple of 64 tokens long (and t_pad == t_seq)");
+        PRAM_REQUIRE(vt->heads > 0 && vt->col0 % 64 == 0 && n == vt->col0 + vt->heads * 64 && ldo16 >= vt->col0,
+                     "pram_linear_x3_qkv_f32: the value heads must be the last heads * 64 columns");
+        p.vt_hi = vt->hi; p.vt_lo = vt->lo; p.vt_col0 = vt->col0; p.vt_heads = vt->heads; p.vt_t = vt->t_seq; p.vt_tv = vt->t_seq;
+    }
     int mi, wn;
     gemm::choose_tile(m, n, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
@@ -682,7 +731,7 @@ extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float
                                   const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
                                   float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                   int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
-    return linear_x3_impl(nullptr, 0, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
+    return linear_x3_impl(nullptr, nullptr, 0, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
                           m, n, alpha, flags, rot_cos, rot_sin, rot_cols, stream);
 }
 
@@ -693,8 +742,21 @@ extern "C" int pram_linear_x3_ragged_f32(const float* a0, int lda0, int k0, cons
                                          float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                          int flags, const float* rot_cos, const float* rot_sin, int rot_cols, const int* lens,
                                          int t_pad, void* stream) {
-    return linear_x3_impl(lens, t_pad, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
+    return linear_x3_impl(nullptr, lens, t_pad, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
                           m, n, alpha, flags, rot_cos, rot_sin, rot_cols, stream);
+}
+
+/* The q | k | v projection of an attention block in one call (nets/segnetvit.py:87-95, nets/gml.py:151-159): columns
+   [0, vt_col0) leave as row-major split planes [m][ldo16] (the q / k operands of pram_attention_x3_f32), the last heads * 64
+   columns — the values — leave as the transposed, key-permuted planes [m / t_seq][heads][64][t_seq] that
+   pram_attention_x3_vt would build from them, zeros for tokens >= lens[s].  t_seq % 64 == 0.  lens may be NULL. */
+extern "C" int pram_linear_x3_qkv_f32(const float* a0, int lda0, int k0, const void* w_hi, const void* w_lo, float w_scale,
+                                      const float* bias, void* out_hi, void* out_lo, int ldo16, void* vt_hi, void* vt_lo, int vt_col0,
+                                      int heads, int t_seq, int m, int n, int flags, const float* rot_cos, const float* rot_sin,
+                                      int rot_cols, const int* lens, void* stream) {
+    VtOut vt{vt_hi, vt_lo, vt_col0, heads, t_seq};
+    return linear_x3_impl(&vt, lens, lens ? t_seq : 0, a0, lda0, k0, nullptr, 0, 0, w_hi, w_lo, w_scale, bias, nullptr, 0, nullptr, 0, out_hi,
+                          out_lo, ldo16, m, n, 1.0f, flags, rot_cos, rot_sin, rot_cols, stream);
 }
 
 extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,

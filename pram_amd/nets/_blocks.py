@@ -78,6 +78,10 @@ def _half_path() -> bool:
     return ops.gemm_precision == "f16" and ops.attention_precision == "f16"
 
 
+import os as _os
+FUSED_VT = _os.environ.get("PRAM_FUSED_VT", "1") != "0"      # the projection epilogue writes the V^T planes (0: separate transpose kernel)
+
+
 def _split_path() -> bool:
     """both families on the split-fp16 path: the projection hands q / k / v over as (hi, lo) fp16 planes"""
     return ops.gemm_precision == "x3" and ops.attention_precision == "x3"
@@ -102,9 +106,12 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
     scale = DH ** -0.5
     if _split_path():
         # split-fp16 path: the projection writes q | k | v as (hi, lo) planes (plus fp32 when the column means need q / k)
-        _, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="only", lens=lens, t_pad=T)
+        if T % 64 == 0 and FUSED_VT:       # the projection writes the values transposed itself
+            pl, v3 = ops.linear_qkv_planes(x, p["qkv_w"], p["qkv_b"], HEADS, T, rotary=(cos, sin, 2 * HEADS * DH), lens=lens)
+        else:
+            _, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), split_out="only", lens=lens, t_pad=T)
+            v3 = ops.value_planes_t(_cols(pl, 2 * hid, 3 * hid), S, HEADS, T, lens)
         q3, k3 = _cols(pl, 0, hid), _cols(pl, hid, 2 * hid)
-        v3 = ops.value_planes_t(_cols(pl, 2 * hid, 3 * hid), S, HEADS, T, lens)
         if want_colmean:
             ctx, lse = ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens, want_lse=True)
             col = ops.attention_colmean_x3(q3, k3, lse, S, HEADS, T, T, scale, lens, lens)
@@ -133,9 +140,12 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
     hid = HEADS * DH
     scale = DH ** -0.5     # (dh^-1/4)^2
     if _split_path():
-        _, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="only", lens=lens, t_pad=T)
+        if T % 64 == 0 and FUSED_VT:
+            pl, v3 = ops.linear_qkv_planes(x, p["qkv_w"], p["qkv_b"], HEADS, T, lens=lens)
+        else:
+            _, pl = ops.linear(x, p["qkv_w"], p["qkv_b"], split_out="only", lens=lens, t_pad=T)
+            v3 = ops.value_planes_t(_cols(pl, hid, 2 * hid), 2 * B, HEADS, T, lens)
         qk3 = _cols(pl, 0, hid)
-        v3 = ops.value_planes_t(_cols(pl, hid, 2 * hid), 2 * B, HEADS, T, lens)
         if want_colmean:
             ctx, lse = ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, want_lse=True, kv_shift=B)
             col = ops.attention_colmean_x3(qk3, qk3, lse, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)

@@ -121,6 +121,30 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def linear_qkv_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, t_seq: int,
+                      rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, lens: Optional[torch.Tensor] = None):
+    """The q | k | v (or qk | v) projection of an attention block on the split-fp16 path, values written transposed:
+    -> ((hi, lo) row-major planes [m, n - heads * 64] of the q / k columns, (vt_hi, vt_lo) = value_planes_t of the value columns).
+    Rows are sequences of t_seq tokens (t_seq % 64 == 0); lens as in linear()."""
+    L = _lib.load()
+    x = x.contiguous()
+    m, k0 = _rows2d(x, "x")
+    n = w.shape[0]
+    col0 = n - heads * 64
+    assert t_seq % 64 == 0 and m % t_seq == 0 and k0 % 32 == 0 and col0 > 0 and col0 % 64 == 0
+    planes = torch.empty(2, m, col0, device=x.device, dtype=torch.float16)
+    vt = torch.empty(2, m // t_seq, heads, 64, t_seq, device=x.device, dtype=torch.float16)
+    flags, rc, rs, rcols = 0, None, None, 0
+    if rotary is not None:
+        rc, rs, rcols = rotary
+        flags = 1
+    if m:
+        wh, wl, ws = split_weight(w.contiguous())
+        _lib.check(L.pram_linear_x3_qkv_f32(_p(x), k0, k0, _p(wh), _p(wl), ws, _p(bias), _p(planes[0]), _p(planes[1]), col0, _p(vt[0]), _p(vt[1]),
+                                            col0, heads, t_seq, m, n, flags, _p(rc), _p(rs), int(rcols), _p(lens), _st()), "pram_linear_x3_qkv_f32")
+    return (planes[0], planes[1]), (vt[0], vt[1])
+
+
 def linear_planes(x, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2=None, residual: Optional[torch.Tensor] = None,
                   alpha: float = 1.0, rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, out: str = "f32"):
     """linear() on the split-fp16 path with the activations ALREADY split: x (and x2) are (hi, lo) pairs of fp16 2-D views

@@ -182,6 +182,32 @@ def test_attention_x3_spike_and_empty(dev):
     assert float(out0.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("S,T,n,ragged", [(3, 320, 768, True), (2, 2048, 768, False), (4, 128, 512, True), (1, 64, 768, False)])
+def test_qkv_projection_writes_the_value_planes_transposed(dev, S, T, n, ragged):
+    """linear_qkv_planes == linear(split_out) + value_planes_t, bit for bit: the q / k columns as row-major planes, the value
+    heads straight into the key-permuted V^T planes (zeros beyond each sequence's length), wide and narrow tiles, with rotary."""
+    from pram_amd import ops
+    heads, hid = 4, 256
+    x = rnd(21, "qkv/x", (S * T, 256)).to(dev)
+    w = rnd(21, "qkv/w", (n, 256), 1.0 / 16).to(dev)
+    b = rnd(21, "qkv/b", (n,), 0.1).to(dev)
+    ang = W.uniform(21, "qkv/a", (S * T, 32), -3.0, 3.0)
+    cos, sin = torch.cos(ang).to(dev), torch.sin(ang).to(dev)
+    rot = (cos, sin, n - hid) if n == 768 else None
+    lens = torch.tensor([T - 37 * i if i % 2 == 0 else max(T - 200, 0) for i in range(S)], dtype=torch.int32, device=dev) if ragged else None
+    _, pl = ops.linear(x, w, b, rotary=rot, split_out="only", lens=lens, t_pad=T if ragged else 0, precision="x3")
+    vt_ref = ops.value_planes_t((pl[0][:, n - hid:], pl[1][:, n - hid:]), S, heads, T, lens)
+    pq, vt = ops.linear_qkv_planes(x, w, b, heads, T, rotary=rot, lens=lens)
+    for s_ in range(S):
+        ln = T if lens is None else int(lens[s_])
+        rows = slice(s_ * T, s_ * T + ln)
+        for pl_i in (0, 1):
+            assert torch.equal(pq[pl_i][rows], pl[pl_i][rows, :n - hid])
+            # positions of whole 64-token blocks that hold a valid token are defined (zeros past the length); later blocks are never read
+            nb = (ln + 63) // 64 * 64
+            assert torch.equal(vt[pl_i][s_, :, :, :nb], vt_ref[pl_i].view(S, heads, 64, -1)[s_, :, :, :nb])
+
+
 @pytest.mark.parametrize("B,M,N,ragged", [(2, 640, 640, False), (3, 300, 517, True), (2, 2048, 2048, True)])
 def test_attention_colmean_x3_vs_fp64(dev, B, M, N, ragged):
     """AdaGML's token scores on the split path: the mean over heads and query rows of the soft-max matrix, from the planes and
