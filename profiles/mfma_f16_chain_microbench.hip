@@ -51,12 +51,21 @@ int main() {
     _Float16 *in; float *out;
     hipMalloc(&in, 65536 * 2 + 64); hipMalloc(&out, 256 * 2048 * 4);
     _Float16* h = (_Float16*)malloc(65536 * 2);
-    for (int z = 0; z < 2; ++z) {
-        for (int i = 0; i < 65536; ++i) h[i] = z ? (_Float16)0.f : (_Float16)((float)rand() / RAND_MAX * 2.f - 1.f);
+    // z = 0 random, 1 zeros, 2 / 3 / 4: random with the low 3 / 6 / 9 mantissa bits cleared (does operand entropy set the power?)
+    for (int z = 0; z < 5; ++z) {
+        for (int i = 0; i < 65536; ++i) {
+            _Float16 v = (_Float16)((float)rand() / RAND_MAX * 2.f - 1.f);
+            if (z == 1) v = (_Float16)0.f;
+            if (z >= 2) { unsigned short b; __builtin_memcpy(&b, &v, 2); b &= (unsigned short)(0xffff << (3 * (z - 1))); __builtin_memcpy(&v, &b, 2); }
+            h[i] = v;
+        }
         hipMemcpy(in, h, 65536 * 2, hipMemcpyHostToDevice);
-        const char* tag = z ? "zero  " : "random";
+        const char* tags[5] = {"random", "zero  ", "rnd-3b", "rnd-6b", "rnd-9b"};
+        const char* tag = tags[z];
         for (int bpc = 1; bpc <= 2; ++bpc) {
-            run<1>(in, out, bpc, tag); run<2>(in, out, bpc, tag); run<4>(in, out, bpc, tag); run<8>(in, out, bpc, tag);
+            if (z >= 2 && bpc == 1) continue;
+            if (z < 2) { run<1>(in, out, bpc, tag); run<2>(in, out, bpc, tag); }
+            run<4>(in, out, bpc, tag); run<8>(in, out, bpc, tag);
         }
     }
     return 0;
