@@ -90,6 +90,64 @@ def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise_frac=
     return ref, torch.stack(gts)
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU during the timed region, read from the amdgpu hwmon files (power1_input in uW,
+    freq1_input in Hz, power1_cap) every 20 ms on a host thread: no tool, no GPU work.  Best effort — any failure gives None.
+    The matrix kernels of this path run AT the board's power cap (profiles/r02_power_probe.txt), which is what bounds them."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        self.dir = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            want = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+            for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if os.path.basename(os.path.realpath(os.path.join(d, "device"))) == want and os.path.exists(os.path.join(d, "power1_input")):
+                    self.dir = d
+                    break
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((self._read("power1_input") * 1e-6, self._read("freq1_input") * 1e-6))
+            except Exception:
+                pass
+            self._stop.wait(0.02)
+
+    def start(self):
+        if self.dir is not None:
+            import threading
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        w = [a for a, _ in self.samples]
+        f = [b for _, b in self.samples]
+        out = {"socket_w_mean": round(sum(w) / len(w), 1), "socket_w_max": round(max(w), 1), "sclk_mhz_mean": round(sum(f) / len(f), 1),
+               "samples": len(w), "source": "amdgpu hwmon power1_input / freq1_input, 20 ms period, timed region only"}
+        try:
+            out["socket_w_cap"] = round(self._read("power1_cap") * 1e-6, 1)
+        except Exception:
+            pass
+        return out
+
+
 def usable_cores() -> int:
     """Cores this process may actually run on: affinity mask capped by the cgroup CPU quota
     (os.cpu_count() reports the host's cores even inside a quota-limited container, and an
@@ -367,11 +425,15 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    sampler = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec = step()
     sync_all()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler is not None else None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -448,6 +510,8 @@ def main():
                        "matches_last_step": n_matches, "matches_correct_last_step": n_correct},
             "roofline": roofline,
         }
+        if power is not None:
+            line["power"] = power
         if parity is not None:
             line["parity"] = parity
         if world == 1 and args.cpu_queries > 0:
