@@ -234,3 +234,21 @@ def test_packed_weights_follow_in_place_parameter_edits(dev):
     net.refresh_packed()
     again = net.produce_matches(_to(data, dev))["matching_scores0"]
     assert H.maxdiff(again, before) < 1e-4
+
+
+def test_profiling_entry_points_are_inert_without_their_switch(dev):
+    """pram_debug_gemm_phases reads (and clears) the wide GEMM's phase counters; without PRAM_GEMM_ABLATE=4 in the environment the
+    product kernels never touch them, so they stay zero across a GEMM."""
+    import ctypes
+    import os
+    from pram_amd import _lib, ops
+    assert os.environ.get("PRAM_GEMM_ABLATE") is None
+    L = _lib.load()
+    buf = (ctypes.c_ulonglong * 72)()
+    _lib.check(L.pram_debug_gemm_phases(buf, 1), "pram_debug_gemm_phases")
+    x = W.normal(51, "dbg/x", (4096, 256)).to(dev)
+    w = W.normal(51, "dbg/w", (512, 256), 1.0 / 16).to(dev)
+    ops.linear(x, w, None, precision="x3")
+    torch.cuda.synchronize()
+    _lib.check(L.pram_debug_gemm_phases(buf, 0), "pram_debug_gemm_phases")
+    assert all(int(v) == 0 for v in buf)
