@@ -55,35 +55,40 @@ def build_models(dev, matcher_name, n_class=113, precision=None):
     return sfd2, seg, matcher, sds
 
 
-def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise_frac=0.25):
+def make_reference_sets(q_desc, q_kpts, q_scores, counts, seed_base, noise_frac=0.25, n_ref=0, m_match=0):
     """the reference set of a query = a permuted copy of its descriptors + noise, re-normalised, the
     last 25 % replaced by outliers (fresh keypoint positions, descriptors drawn around the population mean).  The noise
     (norm = noise_frac x) and the outliers are scaled to the DISCRIMINATIVE part of the descriptors (||d - mean|| ~ 0.18
-    on the synthetic SFD2 weights), not to their unit norm.  Built once, untimed.  Returns (ref, gt) with gt[b, i] = index of query
-    keypoint i's twin in the reference set or -1."""
+    on the synthetic SFD2 weights), not to their unit norm.  Built once, untimed.  n_ref: size of the reference sets (0 = the
+    query size k); m_match: only the first m_match query keypoints enter the matcher (0 = all) — the twins are drawn among
+    those.  Returns (ref, gt) with gt[b, i] = index of query keypoint i's twin in the reference set or -1 (i < m_match)."""
     from pram_amd import weights as W
     B, k, D = q_desc.shape
+    M = m_match or k
+    N = n_ref or k
     dev = q_desc.device
     mu = q_desc.reshape(-1, D).mean(0)
     spread = float((q_desc.reshape(-1, D) - mu).norm(dim=1).mean())
+    n_in = min(N - N // 4, M)
+    n_out = N - n_in
     descs, kps, scs, gts = [], [], [], []
     for b in range(B):
         seed = seed_base + b
-        perm = torch.argsort(W.uniform(seed, "bench/perm", (k,), 0.0, 1.0)).to(dev)
-        d = q_desc[b, perm] + W.normal(seed, "bench/noise", (k, D), noise_frac * spread / D ** 0.5).to(dev)
-        kp = q_kpts[b, perm].clone()
-        n_out = k // 4
-        d[k - n_out:] = mu + W.normal(seed, "bench/out", (n_out, D), spread / D ** 0.5).to(dev)
-        kp[k - n_out:, 0] = torch.floor(W.uniform(seed, "bench/ox", (n_out,), 4.0, W_IMG - 4.0)).to(dev)
-        kp[k - n_out:, 1] = torch.floor(W.uniform(seed, "bench/oy", (n_out,), 4.0, H - 4.0)).to(dev)
+        perm = torch.argsort(W.uniform(seed, "bench/perm", (M,), 0.0, 1.0)).to(dev)
+        src = perm[torch.arange(N, device=dev) % M]
+        d = q_desc[b, src] + W.normal(seed, "bench/noise", (N, D), noise_frac * spread / D ** 0.5).to(dev)
+        kp = q_kpts[b, src].clone()
+        d[n_in:] = mu + W.normal(seed, "bench/out", (n_out, D), spread / D ** 0.5).to(dev)
+        kp[n_in:, 0] = torch.floor(W.uniform(seed, "bench/ox", (n_out,), 4.0, W_IMG - 4.0)).to(dev)
+        kp[n_in:, 1] = torch.floor(W.uniform(seed, "bench/oy", (n_out,), 4.0, H - 4.0)).to(dev)
         descs.append(torch.nn.functional.normalize(d, dim=-1))
         kps.append(kp)
-        scs.append(W.uniform(seed, "bench/sc", (k,), 0.0, 1.0).to(dev))
-        gt = torch.full((k,), -1, dtype=torch.long, device=dev)
-        inl = torch.arange(k - n_out, device=dev)
-        src = perm[:k - n_out]
-        ok = src < counts[b]                       # padded query rows have no twin
-        gt[src[ok]] = inl[ok]
+        scs.append(W.uniform(seed, "bench/sc", (N,), 0.0, 1.0).to(dev))
+        gt = torch.full((M,), -1, dtype=torch.long, device=dev)
+        inl = torch.arange(n_in, device=dev)
+        s_in = src[:n_in]
+        ok = s_in < counts[b]                       # padded query rows have no twin
+        gt[s_in[ok]] = inl[ok]
         gts.append(gt)
     ref = {"descriptors": torch.stack(descs).contiguous(), "keypoints": torch.stack(kps).contiguous(),
            "scores": torch.stack(scs).contiguous()}
@@ -206,11 +211,12 @@ def parity_gate(pipe, sds, matcher_name, images, ref, kpts):
         res["recognise"] = {"logits_maxdiff": float(f"{d_log:.3e}"), "argmax_agreement": round(agree, 6)}
         ok = ok and d_log < 1e-3 and agree == 1.0
         if ref1 is not None:
-            data = {"descriptors0": out["descriptors"][:1, :n].cpu(), "keypoints0": kp[None], "scores0": out["scores"][:1, :n].cpu(),
+            nm = min(n, pipe.match_keypoints) if pipe.match_keypoints else n      # the matcher's share of the query's keypoints
+            data = {"descriptors0": out["descriptors"][:1, :nm].cpu(), "keypoints0": kp[None, :nm], "scores0": out["scores"][:1, :nm].cpu(),
                     "descriptors1": ref1["descriptors"].cpu(), "keypoints1": ref1["keypoints"].cpu(), "scores1": ref1["scores"].cpu(),
                     "image_shape0": (1, 3, W_IMG, H), "image_shape1": (1, 3, W_IMG, H)}
             r = _oracle_matcher(matcher_name)(sds[matcher_name], data)
-            m_got, s_got = out["matches0"][0, :n].cpu(), out["matching_scores0"][0, :n].cpu()
+            m_got, s_got = out["matches0"][0, :nm].cpu(), out["matching_scores0"][0, :nm].cpu()
             m_ref, s_ref = r["matches0"][0], r["matching_scores0"][0]
             d_sc = float((s_got - s_ref).abs().max())
             bad = torch.nonzero(m_got != m_ref).flatten()
@@ -268,14 +274,17 @@ def cpu_baseline(sds, matcher_name, n_queries, kpts, ref_cpu_sets, budget_s=40.0
               file=sys.stderr, flush=True)
     use = times[1:] if len(times) > 1 else times
     best = min(use, key=lambda t: t[0])
+    tot = sorted(t[0] for t in use)
+    median = tot[len(tot) // 2] if len(tot) % 2 else 0.5 * (tot[len(tot) // 2 - 1] + tot[len(tot) // 2])
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": round(1.0 / best[0], 4), "unit": "queries/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / best[0], 4), "value_median": round(1.0 / median, 4), "unit": "queries/s", "cores": cores, "kind": "port",
+            "seconds_per_query": {"min": round(best[0], 3), "median": round(median, 3), "max": round(tot[-1], 3)},
             "stage_seconds": {"extract": round(best[1], 3), "recognise": round(best[2], 3), "match": round(best[3], 3)},
-            "sample": f"{len(use)} full queries (SFD2+sample+SegNetViT+{matcher_name.upper()} {kpts}x{kpts}) after 1 warm-up, fastest; "
-                      f"torch CPU fp32, {cores} threads, {model}"}
+            "sample": f"{len(use)} full queries (SFD2+sample+SegNetViT+{matcher_name.upper()} {kpts}x{ref_cpu_sets['descriptors'].shape[1] if ref_cpu_sets is not None else 0}) "
+                      f"after 1 warm-up: value = fastest, value_median = median; torch CPU fp32, {cores} threads, {model}"}
 
 
 def _free_port() -> int:
@@ -305,31 +314,205 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def attention_roofline(probe, precision, dev, step_ms):
+    """Roofline of the dominant kernel (attention) from the HIP-event probe of one instrumented step.
+
+    Algorithmic FLOPs follow SURVEY.md §8(d): self attention 4 m n 64 per (sequence, head) (= 1024 N^2 per 4-head layer); cross
+    attention 3 * 2 m n 64 per (pair, head) and direction-pair, i.e. 1536 M N per layer — the reference multiplies q k^T ONCE for
+    both directions (nets/gml.py:175-179) while the kernel, like every flash formulation, multiplies it once per direction: the
+    launch executes 4/3 of the algorithmic work and that shows up as a LOWER fraction, not as extra credit.
+    The split-fp16 kernel issues `mfma_per_tile` v_mfma_f32_32x32x16_f16 per 64-key tile where a single-product fp16 attention
+    needs 16 (the library reports 40 = 2.5 per product from 1024 keys on, 48 = 3 below): the fp32-class ceiling of THIS kernel is
+    the fp16 MFMA peak divided by that multiplier."""
+    t_ms, alg, launched, executed = 0.0, 0.0, 0.0, 0.0
+    for ql, kl, mm, nn, hh, bb, e0, e1, kind, mfma_tile in probe:
+        t_ms += e0.elapsed_time(e1)
+        qv = ql.double() if ql is not None else torch.full((bb,), float(mm), dtype=torch.float64, device=dev)
+        kv = kl.double() if kl is not None else torch.full((bb,), float(nn), dtype=torch.float64, device=dev)
+        f = 4.0 * 64 * hh * float((qv * kv).sum().item())       # q k^T + p v of every (sequence, head) the launch computes
+        launched += f
+        alg += f * (0.75 if kind == "cross" else 1.0)
+        executed += f * (mfma_tile / 16.0)
+    n = max(1, len(probe))
+    secs = max(t_ms * 1e-3, 1e-12)
+    achieved = alg / secs / 1e12
+    mult = executed / launched if launched else 1.0              # MFMA flops executed per flop of a one-product kernel
+    pipe_peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+    peak = pipe_peak / mult
+    kern = {"f32": "attention_kernel (v_mfma_f32_32x32x2_f32 flash attention, exact fp32 products)",
+            "x3": "attention_x3_pipe_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per score product, 2 per P.V product from 1024 keys on)",
+            "f16": "attention_x3_pipe_kernel<HI> (C5 fp16 MFMA path: one product)"}[precision]
+    return {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "frac_fp32_class": round(achieved / peak, 4), "frac_fp16_peak": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
+            "mfma_pipe_busy": round(executed / secs / 1e12 / pipe_peak, 4),
+            "mfma_per_product": round(mult, 3), "mfma_pipe_peak": pipe_peak,
+            "flops_convention": "SURVEY 8(d): self 1024 N^2 per layer and sequence, cross 1536 M N per layer and pair (one q.k^T for both directions)",
+            "launched_over_algorithmic_flops": round(launched / alg, 4) if alg else None,
+            "algorithmic_bytes_per_launch": round(launched / n / 512.0), "launches_per_step": len(probe),
+            "avg_launch_ms": round(t_ms / n, 4), "attention_share_of_step": round(t_ms / step_ms, 3) if step_ms else None}
+
+
+def pmc_traffic(precision):
+    """HBM bytes per attention launch from the committed rocprofv3 --pmc passes — only if they were taken on THIS kernel source
+    (profiles/pmc_attention.json records the sha256 of the kernel file it measured); None otherwise."""
+    import hashlib
+    src = {"x3": "attention_x3.hip", "f32": "attention.hip", "f16": "attention_x3.hip"}[precision]
+    try:
+        ent = json.load(open(ROOT / "profiles" / "pmc_attention.json"))[precision]
+        sha = hashlib.sha256((ROOT / "pram_amd" / "csrc" / src).read_bytes()).hexdigest()[:16]
+        if ent.get("kernel_source_sha16") != sha:
+            return None
+        return ent["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+class Job:
+    """One configuration of the hot path on this rank: models, resident inputs, the lanes (streams, optionally one captured
+    hipGraph per lane) and the step function."""
+
+    def __init__(self, dev, rank, world, q0, B, matcher_name, kpts, n_class, stages, inflight, use_graph, precision=None,
+                 ref_kpts=0, match_kpts=0, shard_sizes=None):
+        from pram_amd import ops, weights as Wt
+        from pram_amd.pipeline import GraphedPipeline, QueryPipeline
+        self.dev, self.world, self.B, self.stages, self.matcher_name = dev, world, B, stages, matcher_name
+        self.shard_sizes = shard_sizes
+        self.uneven = shard_sizes is not None and min(shard_sizes) != max(shard_sizes)
+        self.sfd2, self.seg, self.matcher, self.sds = build_models(dev, matcher_name, n_class)
+        for m in (self.sfd2, self.seg, self.matcher):
+            m.set_precision(precision)
+        # the bench keeps several steps in flight: the range guard is read once, after the timed region (guard="deferred")
+        self.pipe = QueryPipeline(self.sfd2, self.seg, self.matcher, max_keypoints=kpts, min_keypoints=128, guard="deferred",
+                                  match_keypoints=match_kpts)
+        self.images = torch.stack([Wt.synthetic_image(q0 + i) for i in range(B)]).to(dev).contiguous()
+        self.do_match = "m" in stages
+        self.ref = self.gt = None
+        with torch.no_grad(), ops.precision_scope(precision):
+            if self.do_match:
+                # synthetic matcher weights calibrated to the extractor's descriptor statistics (weights.calibrate_matcher_input):
+                # without it the untrained matcher sees near-identical tokens and the record holds no matches at all.  Calibrated
+                # on the SAME frame (global query 0) on every rank, so all ranks — and the oracle of the parity gate — share one
+                # set of weights.
+                cal = self.sfd2.extract_batched(Wt.synthetic_image(0)[None].to(dev).contiguous(), self.pipe.cfg)
+                self.sds[matcher_name] = Wt.calibrate_matcher_input(self.sds[matcher_name], cal["descriptors"][0, :int(cal["counts"][0])])
+                self.matcher.load_state_dict(self.sds[matcher_name], strict=True)
+                self.matcher.to(dev).eval()
+                del cal
+            ex = self.sfd2.extract_batched(self.images, self.pipe.cfg)
+            self.counts = ex["counts"].tolist()
+            if self.do_match:
+                self.ref, self.gt = make_reference_sets(ex["descriptors"], ex["keypoints"], ex["scores"], self.counts, 5000 + q0,
+                                                        n_ref=ref_kpts, m_match=match_kpts)
+            del ex
+        self.lanes = [torch.cuda.Stream(device=dev) for _ in range(inflight)] if inflight > 1 else None
+        self.graphs = None
+        if use_graph:
+            # one captured step per lane: the host's share of a step drops from ~3 ms of ctypes launches to one graph launch
+            # (what matters with eight ranks on a cgroup-limited host); GPU work is the same kernels in the same order
+            self.graphs = [GraphedPipeline(self.pipe, self.images, self.ref, stages, record=True) for _ in range(max(1, inflight))]
+        self.issued = 0
+
+    def step(self):
+        from pram_amd.pipeline import QueryPipeline, gather_records
+        sizes = self.shard_sizes if self.uneven else None
+        i = self.issued
+        self.issued += 1
+        if self.lanes is None:
+            if self.graphs is not None:
+                self.graphs[0].replay()
+                rec = self.graphs[0].record
+            else:
+                rec = QueryPipeline.pack_record(self.pipe.run(self.images, self.ref, stages=self.stages))
+            return gather_records(rec, sizes)
+        lane = self.lanes[i % len(self.lanes)]
+        with torch.cuda.stream(lane):
+            if self.graphs is not None:
+                g = self.graphs[i % len(self.graphs)]
+                g.replay()
+                rec = g.record
+            else:
+                rec = QueryPipeline.pack_record(self.pipe.run(self.images, self.ref, stages=self.stages))
+        if self.world == 1:
+            return rec
+        # the (tiny) all-gather stays on the one main stream, in step order on every rank: RCCL never sees
+        # collectives of one communicator issued from several streams
+        main_s = torch.cuda.current_stream(self.dev)
+        main_s.wait_stream(lane)
+        rec.record_stream(main_s)
+        full = gather_records(rec, sizes)
+        lane.wait_stream(main_s)          # a captured record buffer is rewritten by the lane's next replay: not before the gather read it
+        return full
+
+    def timed(self, steps, warmup, sync_all):
+        for _ in range(warmup):
+            self.step()
+        sync_all()
+        t0 = time.perf_counter()
+        rec = None
+        for _ in range(steps):
+            rec = self.step()
+        sync_all()
+        return time.perf_counter() - t0, rec
+
+
+def pin_rank_thread(local: int, world: int):
+    """One host core per rank (the launching thread), spread over the cores this job may use: eight ranks otherwise migrate over
+    a cgroup-limited core set and a descheduled rank stalls the step's barrier.  -> the core, or None."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) < world:
+            return None
+        core = allowed[(local * len(allowed)) // world]
+        os.sched_setaffinity(0, {core})
+        return core
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 100 with --latency)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 6; 30 with --latency)")
     ap.add_argument("--batch-per-gpu", type=int, default=16,
                     help="queries per GPU per step (BASELINE configs[1]: batch = 16 on one MI355X; weak scaling keeps it per GPU)")
     ap.add_argument("--batch-total", type=int, default=0,
                     help="total queries per step, sharded over the ranks (BASELINE configs[2]: 64 over 8 GPUs; configs[4]: 128 "
                          "over 8); strong scaling; overrides --batch-per-gpu; uneven shards are fine")
     ap.add_argument("--kpts", type=int, default=2048)
+    ap.add_argument("--ref-kpts", type=int, default=0, help="size of the reference keypoint sets the matcher sees (0 = --kpts)")
+    ap.add_argument("--match-kpts", type=int, default=0,
+                    help="only the best M keypoints of a query enter the matcher (0 = all): with --ref-kpts 1024 the secondary "
+                         "512 x 1024 matcher shape of SURVEY.md 8(d) (recognition/recmap.py:670-692, multimap3d.py:131-139)")
     ap.add_argument("--n-class", type=int, default=113, help="landmark classes (7Scenes 113, Cambridge 161, Aachen 513)")
     ap.add_argument("--matcher", default="gml", choices=["gml", "adagml"])
     ap.add_argument("--stages", default="erm", help="e=extract r=recognise m=match")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="batches in flight per GPU: consecutive steps are issued round-robin on this many HIP streams, so the "
-                         "HBM-bound kernels of one batch run under the MFMA-bound kernels of the next (throughput mode)")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="batches in flight per GPU (default 3; 1 with --latency): consecutive steps are issued round-robin on this "
+                         "many HIP streams, so the HBM-bound kernels of one batch run under the MFMA-bound kernels of the next")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay one captured hipGraph per lane instead of ~330 ctypes launches per step (auto: on for --gpus > 1 "
+                         "and --latency, where the host thread matters; the GPU work is identical)")
+    ap.add_argument("--latency", action="store_true",
+                    help="the reference's online loop (localization/loc_by_rec_online.py:109-133): ONE query per step, one step at "
+                         "a time, graph replay; ms_per_step is the per-query latency")
     ap.add_argument("--cpu-queries", type=int, default=4, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate (kernel profiling runs)")
+    ap.add_argument("--alt", default="auto", choices=["auto", "on", "off"],
+                    help="also time, in the same run (3 steps each), AdaGML, the exact-fp32 path, the secondary 512 x 1024 matcher "
+                         "shape and the one-query latency, and report them as 'alt' (auto: on for the default 1-GPU configuration)")
     ap.add_argument("--precision", default=None, choices=["f32", "x3", "f16"],
                     help="MFMA path of the three matrix families: f32 = v_mfma_f32_32x32x2_f32 (exact fp32 products); "
                          "x3 = split-fp16, three v_mfma_f32_32x32x16_f16 per product (fp32-class accuracy, passes the fp32 "
                          "parity gate); f16 = BASELINE C5 'fp16 MFMA path' (single fp16 product, own tolerance, not the "
                          "headline).  Default: the package default (pram_amd.ops.default_precision)")
     args = ap.parse_args()
+    if args.latency:
+        args.batch_per_gpu, args.batch_total = 1, 0
+    steps = args.steps if args.steps is not None else (100 if args.latency else 20)
+    warmup = args.warmup if args.warmup is not None else (30 if args.latency else 6)
+    inflight = args.inflight if args.inflight is not None else (1 if args.latency else 3)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
@@ -344,6 +527,7 @@ def main():
     # PRAM_BENCH_ONE_DEVICE=1 (test hook): every rank uses GPU 0 over gloo, to exercise the multi-rank control flow
     # (barriers, result gather, max-over-ranks timing) on a one-GPU box; never set by the driver
     one_device = os.environ.get("PRAM_BENCH_ONE_DEVICE") == "1"
+    core = pin_rank_thread(local, world) if world > 1 else None
     if one_device:
         local = 0
     elif torch.cuda.device_count() <= local:
@@ -358,13 +542,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)     # backend 'nccl' is RCCL on ROCm
 
-    from pram_amd import ops, weights as Wt
-    from pram_amd.pipeline import QueryPipeline, gather_records, shard_range
+    from pram_amd import ops
+    from pram_amd.pipeline import shard_range
     if args.precision:
         ops.set_precision(args.precision)
-    precision = ops.current_precision()
-    sfd2, seg, matcher, sds = build_models(dev, args.matcher, args.n_class)
-    pipe = QueryPipeline(sfd2, seg, matcher, max_keypoints=args.kpts, min_keypoints=128)
+    if ops.attention_precision != ops.gemm_precision:
+        raise SystemExit(f"bench.py: PRAM_GEMM_PRECISION={ops.gemm_precision} and PRAM_ATTENTION_PRECISION={ops.attention_precision} "
+                         f"differ — the line reports ONE arithmetic (use --precision / PRAM_PRECISION)")
+    precision = ops.gemm_precision
+    use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or args.latency))
 
     if args.batch_total > 0:
         spans = [shard_range(args.batch_total, r, world) for r in range(world)]
@@ -378,43 +564,6 @@ def main():
     total_per_step = sum(shard_sizes)
     if B == 0:
         raise SystemExit(f"bench.py: rank {rank} has no queries (--batch-total {args.batch_total} over {world} ranks)")
-    images = torch.stack([Wt.synthetic_image(q0 + i) for i in range(B)]).to(dev).contiguous()
-    do_match = "m" in args.stages
-    ref = gt = None
-    with torch.no_grad():
-        ex = sfd2.extract_batched(images, pipe.cfg)
-        counts = ex["counts"].tolist()
-        if do_match:
-            # synthetic matcher weights calibrated to the extractor's descriptor statistics (weights.calibrate_matcher_input):
-            # without it the untrained matcher sees near-identical tokens and the record holds no matches at all
-            sds[args.matcher] = Wt.calibrate_matcher_input(sds[args.matcher], ex["descriptors"][0, :counts[0]])
-            matcher.load_state_dict(sds[args.matcher], strict=True)
-            matcher.to(dev).eval()
-            ref, gt = make_reference_sets(ex["descriptors"], ex["keypoints"], ex["scores"], counts, 5000 + q0)
-    del ex
-
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
-    issued = [0]
-    uneven = min(shard_sizes) != max(shard_sizes)
-
-    def step():
-        if lanes is None:
-            out = pipe.run(images, ref, stages=args.stages)
-            rec = QueryPipeline.pack_record(out)
-            return gather_records(rec, shard_sizes if uneven else None)
-        lane = lanes[issued[0] % len(lanes)]
-        issued[0] += 1
-        with torch.cuda.stream(lane):
-            out = pipe.run(images, ref, stages=args.stages)
-            rec = QueryPipeline.pack_record(out)
-        if world == 1:
-            return rec
-        # the (tiny) all-gather stays on the one main stream, in step order on every rank: RCCL never sees
-        # collectives of one communicator issued from several streams
-        main_s = torch.cuda.current_stream(dev)
-        main_s.wait_stream(lane)
-        rec.record_stream(main_s)
-        return gather_records(rec, shard_sizes if uneven else None)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -422,98 +571,130 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    job = Job(dev, rank, world, q0, B, args.matcher, args.kpts, args.n_class, args.stages, inflight, use_graph,
+              ref_kpts=args.ref_kpts, match_kpts=args.match_kpts, shard_sizes=shard_sizes)
+    pipe, sds, images, ref, gt, counts, do_match = job.pipe, job.sds, job.images, job.ref, job.gt, job.counts, job.do_match
+
+    for _ in range(warmup):
+        job.step()
     sync_all()
     sampler = PowerSampler(dev.index if dev.index is not None else 0) if rank == 0 else None
     if sampler is not None:
         sampler.start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec = step()
+    for _ in range(steps):
+        rec = job.step()
     sync_all()
     dt = time.perf_counter() - t0
     power = sampler.stop() if sampler is not None else None
+    rank_ms = [dt / steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) / steps * 1e3 for x in allt]
+        dt = max(float(x.item()) for x in allt)
     assert rec.shape[0] == total_per_step, (rec.shape, total_per_step)
     local_rec = rec[q0 - spans[0][0]:q1 - spans[0][0]] if world > 1 else rec
     n_matches = int((local_rec[:, :, 4] >= 0).sum().item())
     n_correct = 0
     if do_match:
-        m0 = local_rec[:, :, 4].long()
+        km = gt.shape[1]
+        m0 = local_rec[:, :km, 4].long()
+        n_matches = int((m0 >= 0).sum().item())
         n_correct = int(((m0 == gt) & (m0 >= 0)).sum().item())
         n_inliers = int((gt >= 0).sum().item())
         # the workload is built so that a known share of the twins is recovered; an empty record means it degenerated
         if n_matches < 0.1 * n_inliers:
             raise SystemExit(f"bench.py: degenerate matcher workload ({n_matches} matches for {n_inliers} planted twins)")
+    # range guard of the split-fp16 path: the timed steps ran "deferred" (several in flight) — read it once, now
+    range_hit = ops.x3_range_exceeded(dev) if precision == "x3" else False
 
-    # ---- roofline of the dominant kernel (attention), one extra instrumented step, HIP events on the launch stream
-    lanes = None                      # the instrumented step runs alone on the current stream
+    # ---- roofline of the dominant kernel (attention), one extra instrumented EAGER step, HIP events on the launch stream
+    lanes_saved, graphs_saved = job.lanes, job.graphs
+    job.lanes = job.graphs = None                      # the instrumented step runs alone on the current stream
     torch.cuda.synchronize()
     ops.attention_probe = []
-    step()
+    job.step()
     torch.cuda.synchronize()
     probe, ops.attention_probe = ops.attention_probe, None
-    attn_ms, attn_flops = 0.0, 0.0
-    for ql, kl, mm, nn, hh, bb, e0, e1 in probe:
-        attn_ms += e0.elapsed_time(e1)
-        qv = ql.double() if ql is not None else torch.full((bb,), float(mm), dtype=torch.float64, device=dev)
-        kv = kl.double() if kl is not None else torch.full((bb,), float(nn), dtype=torch.float64, device=dev)
-        attn_flops += 4.0 * 64 * hh * float((qv * kv).sum().item())
-    achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
-    traffic = None
-    if (args.kpts, B, args.matcher, args.stages, args.n_class) == (2048, 16, "gml", "erm", 113):
-        try:   # HBM bytes per attention launch of THIS configuration, from the committed rocprofv3 --pmc passes
-            traffic = json.load(open(ROOT / "profiles" / "pmc_attention.json"))[precision]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-    # ceiling on ALGORITHMIC attention flops (4 M N 64 per head): the f32 MFMA peak; a third of the f16 MFMA peak on
-    # the split path (three fp16 MFMAs per fp32-class product); the f16 MFMA peak on the single-product C5 path
-    kern, peak, mult = {
-        "f32": ("attention_kernel (v_mfma_f32_32x32x2_f32 flash attention)", PEAK_F32_MFMA_TFLOPS, 1),
-        "x3": ("attention_x3_pipe_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product)", PEAK_F16_MFMA_TFLOPS / 3.0, 3),
-        "f16": ("attention_h16_kernel (C5 fp16 MFMA path)", PEAK_F16_MFMA_TFLOPS, 1),
-    }[precision]
-    roofline = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "mfma_flops_executed_per_algorithmic_flop": mult, "mfma_pipe_peak": PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS,
-                "algorithmic_bytes_per_launch": round(attn_flops / max(1, len(probe)) / 512.0), "launches_per_step": len(probe),
-                "avg_launch_ms": round(attn_ms / max(1, len(probe)), 4),
-                "attention_share_of_step": round(attn_ms / (dt / args.steps * 1e3), 3)}
+    job.lanes, job.graphs = lanes_saved, graphs_saved
+    roofline = attention_roofline(probe, precision, dev, dt / steps * 1e3)
+    default_shape = (args.kpts, B, args.matcher, args.stages, args.n_class, args.ref_kpts, args.match_kpts) == (2048, 16, "gml", "erm", 113, 0, 0)
+    roofline["traffic"] = pmc_traffic(precision) if default_shape else None
+    roofline["traffic_source"] = ("profiles/pmc_attention.json (rocprofv3 --pmc passes of this kernel source: 2 x FETCH_SIZE + WRITE_SIZE)"
+                                  if roofline["traffic"] is not None else None)
 
     parity = None
     if rank == 0 and not args.no_parity and "e" in args.stages and "r" in args.stages:
+        pipe.guard = "fallback"
         parity = parity_gate(pipe, sds, args.matcher, images, ref, args.kpts)
+        pipe.guard = "deferred"
         print(f"[bench] parity: {json.dumps(parity)}", file=sys.stderr, flush=True)
 
+    # ---- other configurations of the same path, measured in this run (rank 0, N = 1): what the driver otherwise never sees
+    alt = None
+    want_alt = args.alt == "on" or (args.alt == "auto" and default_shape and world == 1 and precision == "x3" and not args.latency)
+    if rank == 0 and world == 1 and want_alt:
+        alt = {}
+
+        def alt_run(name, note, steps_=3, warm_=2, **kw):
+            cfg = dict(matcher_name=args.matcher, kpts=args.kpts, n_class=args.n_class, stages=args.stages, inflight=inflight,
+                       use_graph=False, precision=None, ref_kpts=0, match_kpts=0)
+            cfg.update(kw)
+            Bq = cfg.pop("B", B)
+            try:
+                j = Job(dev, 0, 1, 0, Bq, **cfg)
+                t, _ = j.timed(steps_, warm_, sync_all)
+                hit = ops.x3_range_exceeded(dev) if (cfg["precision"] or precision) == "x3" else False
+                alt[name] = {"queries_per_s": round(Bq * steps_ / t, 2), "ms_per_step": round(t / steps_ * 1e3, 3), "steps": steps_, "what": note}
+                if hit:
+                    alt[name]["x3_range_exceeded"] = True
+                del j
+            except Exception as e:      # an alternative that fails must not take the headline line with it — but it is reported
+                alt[name] = {"error": f"{type(e).__name__}: {e}"[:300], "what": note}
+            torch.cuda.empty_cache()
+
+        alt_run("adagml", "same step with the AdaGML matcher (BASELINE configs[2] names it; pruning / early exit are data-dependent)", matcher_name="adagml")
+        alt_run("exact_f32", "same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)", precision="f32")
+        alt_run("gml_512x1024", "secondary matcher shape of SURVEY 8(d): the 512 best keypoints of a query against 1024-keypoint reference sets",
+                ref_kpts=1024, match_kpts=512)
+        alt_run("latency_b1", "one query per step, one step at a time, captured hipGraph replayed (the reference's online loop); ms_per_step = per-query latency",
+                steps_=30, warm_=10, B=1, inflight=1, use_graph=True)
+
     if rank == 0:
-        total_q = total_per_step * args.steps
+        total_q = total_per_step * steps
         dtype = {"f32": "f32", "x3": "f32 results via split-fp16 MFMA (f16 x3 products, f32 accumulate)",
                  "f16": "f16 operands / f32 accumulate: BASELINE C5 'fp16 MFMA path', NOT the fp32 parity configuration"}[precision]
+        rk = args.ref_kpts or args.kpts
         line = {
             "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})",
             "value": round(total_q / dt, 3), "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{'7Scenes' if args.n_class == 113 else 'custom'} full hot path: SFD2 extract+sample -> SegNetViT nc{args.n_class} (15 layers) -> "
-                                   f"{args.matcher.upper()} match + 20 Sinkhorn iters vs a {args.kpts}-kpt reference set; "
-                                   f"stages={args.stages}",
+                                   f"{args.matcher.upper()} match + 20 Sinkhorn iters, {args.match_kpts or args.kpts} query kpts vs a {rk}-kpt reference set; "
+                                   f"stages={args.stages}" + ("; latency mode: one query at a time" if args.latency else ""),
                        "precision": precision,
-                       "queries_per_step": total_per_step, "queries_per_gpu_per_step": shard_sizes if uneven else B,
-                       "batches_in_flight_per_gpu": max(1, args.inflight),
+                       "queries_per_step": total_per_step, "queries_per_gpu_per_step": shard_sizes if job.uneven else B,
+                       "batches_in_flight_per_gpu": max(1, inflight), "hipgraph_replay": bool(use_graph),
                        "frame": f"{W_IMG}x{H}", "keypoints": args.kpts,
                        "keypoints_found": counts[:4], "parallelism": f"query-sharded x{world}, one all-gather of result records",
                        "matches_last_step": n_matches, "matches_correct_last_step": n_correct},
             "roofline": roofline,
+            "range_guard": {"x3_range_exceeded": bool(range_hit),
+                            "policy": "deferred: the status word is read once after the timed region (steps in flight); set = the line is void"},
         }
+        if world > 1:
+            line["per_rank_ms_per_step"] = [round(x, 3) for x in rank_ms]
+            line["config"]["host_core_of_rank0"] = core
         if power is not None:
             line["power"] = power
         if parity is not None:
             line["parity"] = parity
+        if alt is not None:
+            line["alt"] = alt
         if world == 1 and args.cpu_queries > 0:
             ref_cpu_sets = None if ref is None else {k: v.cpu() for k, v in ref.items()}
             line["cpu_baseline"] = cpu_baseline(sds, args.matcher, args.cpu_queries, args.kpts, ref_cpu_sets)
@@ -521,6 +702,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if range_hit:
+        raise SystemExit("bench.py: the split-fp16 path met an activation beyond its range (range_guard) — the timed steps are void")
     if parity is not None and not parity["ok"]:
         raise SystemExit("bench.py: PARITY GATE FAILED (see the 'parity' object of the JSON line)")
 

@@ -24,7 +24,9 @@
  *     or all of them (max_keypoints >= h * w);
  *   - AdaGML pruning handles token sets of at most 8192 tokens (pram_adagml_prune_f32);
  *   - LayerNorm rows are at most 1024 wide; the split-fp16 GEMMs need K % 32 == 0 (other shapes: the exact-fp32 entry);
- *   - the split-fp16 operands carry value * 16 in fp16: |x| must stay below 4094 (activations of the three networks are O(10)).
+ *   - the split-fp16 operands carry value * 16 in fp16: a finite |x| >= 4094.97 does not fit.  This one is NOT a silent limit
+ *     either: see "range guard" below (pram_set_status_word) — the kernels report it, and pram_amd's Python layer re-runs the
+ *     call on the exact-fp32 entries (or raises).
  */
 #ifndef PRAM_HIP_H
 #define PRAM_HIP_H
@@ -43,6 +45,20 @@ extern "C" {
 
 int pram_hip_version(void);
 const char* pram_last_error(void);
+
+/* ---------------------------------------------------------------- range guard of the split-fp16 ("x3") entries
+ * The x3 entries carry every fp32 activation as two fp16 parts of value * 16.  A finite value with |16 x| >= 65520 rounds to
+ * +-inf in its hi part and the result of the launch is garbage (usually NaN — but NaN scores turn into ordinary-looking
+ * indices further down).  Kernel launches are asynchronous, so this cannot come back as a return code of the launch: every x3
+ * kernel that splits fp32 values (GEMM / convolution operand staging, the plane-writing epilogues) ORs PRAM_STATUS_X3_RANGE
+ * into a caller-owned DEVICE status word when it meets such a value.  The word is sticky until reset.  NaN inputs are not
+ * flagged: they propagate as NaN, exactly as in the reference's fp32 arithmetic; +-inf inputs are flagged.
+ *   pram_set_status_word : registers the word for the CURRENT device (NULL detaches; without a word nothing is reported).
+ *   pram_read_status_word: enqueues a copy of the word to *host_out on `stream`, waits for the stream, and (reset != 0) clears
+ *                          the word if it was set.  A caller that sees PRAM_STATUS_X3_RANGE re-runs on the *_f32 entries. */
+#define PRAM_STATUS_X3_RANGE 1u
+int pram_set_status_word(unsigned int* device_word);
+int pram_read_status_word(unsigned int* host_out, int reset, void* stream);
 
 /* ---------------------------------------------------------------- token linear algebra */
 
@@ -200,12 +216,31 @@ int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, c
  * sites as pram_attention_f32).  q / k are row-major split planes written by pram_linear_x3_f32 (value * 16 = hi + lo,
  * ld* in halves, multiples of 8; heads are 64-wide column blocks); vt_hi / vt_lo are the TRANSPOSED value planes of the
  * key side built by pram_attention_x3_vt: [batch][heads][64][tv], tv = n_max rounded up to 64.  S = K Q^T and O = P V are
- * three fp16 MFMAs per product with fp32 accumulation, the probabilities are split in registers.  Output fp32.
- * kv_shift as in pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs). */
+ * fp16 MFMAs with fp32 accumulation: three per product for the scores; two per product for P V from 1024 keys on (the
+ * probabilities enter as one fp16), three below (pram_attention_x3_mfma_per_tile).  Output fp32.
+ * kv_shift as in pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs).
+ * Key chunks: from 1024 keys on the keys are reduced in chunks (pram_attention_x3_set_chunk_keys: default 2048 keys), each chunk
+ * normalised, parked in `workspace` (pram_attention_x3_workspace_bytes; 0 when a sequence is a single chunk) and folded in chunk
+ * order.  One workgroup normally walks all chunks of its 128 query rows; an under-filled launch (pram_attention_x3_is_split: one or
+ * two query frames, the reference's online loop localization/loc_by_rec_online.py:109-133) runs groups of chunks as a second grid
+ * dimension and folds them in a second kernel: the SAME fold in the SAME order, so the output is bit-identical whichever mode
+ * ran.  workspace == NULL (or too small) with more than one chunk: fused with the running fold in registers — same bits, slower. */
+size_t pram_attention_x3_workspace_bytes(int batch, int heads, int m_max, int n_max);
+int pram_attention_x3_is_split(int batch, int heads, int m_max, int n_max);
+/* tuning / test knob: under-filled launches are split along the keys into as many groups of 512-key chunks as bring the grid to
+ * `workgroups` (default 256 = one per CU; 0 = never; negative restores the default); returns the previous value.  The mode never
+ * changes a result bit.  pram_attention_x3_is_split returns the number of groups (1 = fused). */
+int pram_attention_x3_set_split_target(int workgroups);
+/* keys per chunk (a multiple of 128; default 2048 or the environment's PRAM_ATTN_CHUNK_KEYS), process-wide: set it before the first
+ * launch — it fixes where EVERY launch folds its partial soft-maxes (results move in their last bits, consistently for all batch
+ * sizes).  Smaller chunks let shorter key sets use the split mode; a fused walk pays for every chunk it parks (+3..8 % kernel time
+ * at 1024 keys per chunk, +13 % at 512, for 2048-key sets).  0 = query; returns the value in force. */
+int pram_attention_x3_set_chunk_keys(int keys);
+int pram_attention_x3_mfma_per_tile(int n_max);
 int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
                           const void* vt_hi, const void* vt_lo, float* out, int ldo, float* lse2,
                           const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
-                          float scale, int kv_shift, void* stream);
+                          float scale, int kv_shift, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Column means of the soft-max matrix of the pram_attention_x3_f32 call that produced lse2 (AdaGML's token scores,
  * nets/adagml.py:92-104): colmean[kb][j] = mean over heads and over the q_lens[b] query rows of softmax_row(scale q k^T)[i][j],
@@ -425,6 +460,16 @@ int pram_proj_dist_top2_f64uv(const float* sim, int ld, const float* kpts, const
  * columns valid); count = number of survivors (device int). */
 int pram_project_points_f64(const double* xyz, const double* K, const double* Tcw, int n, double im_w, double im_h,
                             double* uvd, int* mask, int* keep_idx, double* uv_keep, int* count, void* stream);
+
+/* Fixed-size per-query result record rec [batch][k][6] fp32 = x, y, score, landmark id, match index, match score — what the
+ * single all-gather of the query-sharded job carries (the reference hands the same fields to its pose solver,
+ * localization/singlemap3d.py:155-170).  landmark (int32 [batch][k]) and matches0 / mscores0 (int64 / fp32 [batch][km], km <= k:
+ * only the first km keypoints of a query went through the matcher) may be NULL: 0, and -1 / 0 beyond km. */
+int pram_pack_record_f32(const float* kpts, const float* scores, const int* landmark, const long long* matches0,
+                         const float* mscores0, int batch, int k, int km, float* rec, void* stream);
+
+/* dst[0 .. count) <- value, 32-bit words, on the stream (torch.zeros / torch.full of the host-side glue without a framework kernel). */
+int pram_fill_u32(void* dst, unsigned int value, size_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,9 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpram_hip.so"
+import os as _os
+# PRAM_HIP_LIB: an alternative build of the same library (A/B timing of build options under profiles/); never set in production
+_LIB_PATH = Path(_os.environ["PRAM_HIP_LIB"]) if _os.environ.get("PRAM_HIP_LIB") else Path(__file__).resolve().parent / "csrc" / "libpram_hip.so"
 _lib = None
 
 P = C.c_void_p
@@ -19,6 +21,8 @@ SZ = C.c_size_t
 _SIGS = {
     "pram_hip_version": (I, []),
     "pram_last_error": (C.c_char_p, []),
+    "pram_set_status_word": (I, [P]),
+    "pram_read_status_word": (I, [P, I, P]),
     "pram_linear_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_f16_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_f16_h16": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, F, I, P, P, I, P]),
@@ -29,7 +33,12 @@ _SIGS = {
     "pram_linear_x3_qkv_f32": (I, [P, I, I, P, P, F, P, P, P, I, P, P, I, I, I, I, I, I, P, P, I, P, P]),
     "pram_layernorm_gelu_ragged_f32": (I, [P, I, P, I, P, P, I, I, F, P, I, P]),
     "pram_linear_x3p_f32": (I, [P, P, I, I, P, P, I, I, P, P, F, P, P, I, P, I, P, P, I, I, I, F, I, P, P, I, P]),
-    "pram_attention_x3_f32": (I, [P, P, I, P, P, I, P, P, P, I, P, P, P, I, I, I, I, F, I, P]),
+    "pram_attention_x3_f32": (I, [P, P, I, P, P, I, P, P, P, I, P, P, P, I, I, I, I, F, I, P, SZ, P]),
+    "pram_attention_x3_workspace_bytes": (SZ, [I, I, I, I]),
+    "pram_attention_x3_mfma_per_tile": (I, [I]),
+    "pram_attention_x3_is_split": (I, [I, I, I, I]),
+    "pram_attention_x3_set_split_target": (I, [I]),
+    "pram_attention_x3_set_chunk_keys": (I, [I]),
     "pram_attention_x3_colmean_f32": (I, [P, P, I, P, P, I, P, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_h16t_f32": (I, [P, I, P, I, P, P, I, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_x3_vt": (I, [P, P, I, P, P, P, I, I, I, P]),
@@ -71,6 +80,8 @@ _SIGS = {
     "pram_proj_dist_top2_f64uv": (I, [P, I, P, P, I, I, I, C.c_double, P, P, P, P]),
     "pram_project_points_f64": (I, [P, P, P, I, C.c_double, C.c_double, P, P, P, P, P, P]),
     "pram_seg_vote": (I, [P, P, I, I, I, P, P, P, P, P, P, P]),
+    "pram_pack_record_f32": (I, [P, P, P, P, P, I, I, I, P, P]),
+    "pram_fill_u32": (I, [P, C.c_uint, SZ, P]),
     "pram_score_lookup_f32": (I, [P, LL, I, I, P, P, I, I, P, P]),
 }
 

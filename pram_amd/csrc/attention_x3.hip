@@ -39,7 +39,38 @@ struct ArgsX {
     int q_tiles;
     int kv_shift;                    // as in attention.hip
     float in_scale;                  // scale of the planes in the single-product mode (1: plain fp16 q / k / v)
+    int nsplit;                      // 1: a workgroup walks all key chunks; > 1: blockIdx.y = group of group_tiles / 8 key chunks
+    int group_tiles;                 // split mode: 64-key tiles per workgroup (a multiple of chunk_tiles)
+    int chunk_tiles;                 // 64-key tiles per key chunk (g_chunk_tiles: even, the same for every launch of the process)
+    float* part_o;                   // [nsplit][batch * m_max][heads * D]   normalised chunk outputs
+    float* part_l;                   // [nsplit][batch][heads][m_max]        their log2-sum-exp
 };
+
+// Key chunks (as attention.hip).  From 1024 keys on, the keys of a sequence are processed in chunks of chunk_tiles tiles: every
+// chunk runs the online soft-max from a fresh state, is normalised, and all chunks are folded by fold_weights / fold_value — a
+// fixed left fold in chunk order.  One workgroup normally walks all chunks of its 128 query rows ("fused").  A launch with too
+// few (batch, head, q-tile) units to fill the chip — one or two query frames, the reference's online loop
+// (localization/loc_by_rec_online.py:109-133) — makes groups of chunks a grid dimension instead ("split"): each workgroup parks
+// its normalised chunk results in a caller-owned workspace and combine_x3_kernel applies the SAME fold in the SAME order, so the
+// output does not depend on which mode ran, bit for bit: a padded batch element still equals its B = 1 run exactly.
+// Chunk size.  A fused walk parks every chunk but its last (fp32, 8 KB per wave and chunk: the running fold does not fit in the
+// 256 registers of a wave beside the pipeline's two score tiles) and reads them back once at the end.  At the power cap bytes are
+// time: 512-key chunks cost +13 % kernel time at 2048 keys, 1024-key chunks +3...8 % (profiles/r03_x3_attention_chunks.txt).  The
+// default is therefore 2048 keys — the shipped 2048-keypoint configurations run one chunk and pay nothing, 4096 keys run two — and
+// pram_attention_x3_set_chunk_keys lowers it for deployments that want the split mode at 2048 keys (it moves the chunk
+// boundaries of EVERY launch, so results change in their last bits consistently, never between batch sizes).
+constexpr int DEFAULT_CHUNK_TILES = 32;         // 2048 keys (g_chunk_tiles; pram_attention_x3_set_chunk_keys)
+constexpr int SPLIT_TARGET = 256;               // split launches aim at this many workgroups: one per CU (g_split_target)
+
+__device__ __forceinline__ void fold_weights(float lt, float lc, float* at, float* ac, float* lnew) {
+    const float mx = fmaxf(lt, lc);
+    const float wt = exp2f(lt - mx), wc = exp2f(lc - mx);
+    const float den = wt + wc;
+    *at = wt / den;
+    *ac = wc / den;
+    *lnew = mx + log2f(den);
+}
+__device__ __forceinline__ float fold_value(float ot, float oc, float at, float ac) { return ot * at + oc * ac; }
 
 struct alignas(16) Smem {
     _Float16 kh[2][BKV * D];    // [key][d], slot-swizzled
@@ -303,7 +334,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
 // the kernel above; the soft-max is written with packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32).
 // HI: single-product mode (BASELINE C5's fp16 path): only the hi planes exist (q / k / v rounded to fp16, scale p.in_scale = 1),
 // one MFMA per product; half the LDS, so the co-residency is bounded by registers only.
-template <bool PSPLIT, bool HI = false>
+// MODE 0: one online soft-max over all keys (short key sets: PSPLIT, always fused); 1: fused, key chunks parked in the workspace
+// and folded at the end; 2: split — blockIdx.y = key chunk, the chunk result goes to the workspace, combine_x3_kernel folds;
+// 3: fused without a workspace (running fold in registers / scratch: slower) — see "Key chunks" above.
+template <bool PSPLIT, bool HI = false, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     static_assert(!(HI && PSPLIT), "the single-product mode carries one plane of everything");
     __shared__ typename SmemSel<HI>::type s;
@@ -325,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     const bool wave_active = q0 < qlen;
     const int qrow = q0 + r;
     const bool q_ok = qrow < qlen;
-    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip)
+    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip); the split mode's first chunk reports it
+        if (MODE == 2 && blockIdx.y != 0) return;
         if (q_ok) {
             float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
 #pragma unroll
@@ -417,13 +452,146 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         }
     };
 
-    const int nkt = (klen + BKV - 1) / BKV;
+    const int nkt_all = (klen + BKV - 1) / BKV;
+    const int CT = p.chunk_tiles;
+    const int t0 = MODE == 2 ? (int)blockIdx.y * p.group_tiles : 0;               // first tile of this workgroup (a multiple of 8)
+    const int nkt = MODE == 2 ? min(nkt_all, t0 + p.group_tiles) : nkt_all;       // one past its last tile
+    if (t0 >= nkt) return;                                                         // this chunk lies beyond klen
     float m_run = -1.0e30f, l_run = 0.f;
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
     half8 ph[2][2], pl[2][2];
-
+    // Chunk bookkeeping.  MODE 1 (fused): the normalised result of every finished chunk but the last is PARKED in the workspace —
+    // the same [chunk][row][head * 64 + d] / [chunk][batch][head][row] layout the split mode writes — and folded after the last
+    // tile, by the left fold combine_x3_kernel applies: a running total in registers does not fit beside the two score tiles of
+    // the software pipeline (256 registers at two waves per SIMD; kept there by the compiler it is spilled and reloaded with the
+    // latency exposed at every chunk end: +15 % kernel time = MODE 3, the fallback without a workspace), parked it costs stores
+    // only and one exposed round trip per workgroup.  MODE 0 / 2: one chunk per workgroup.
+    float l_tot2 = -INFINITY;
+    float o_tot[2][MODE == 3 ? 16 : 1];
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o_tot[0][e] = 0.f; o_tot[1][e] = 0.f; }
+    }
+    // The workspace addresses are recomputed where they are used, behind an opaque zero: hoisted out of the tile loop they would be
+    // four more registers live across it — spilled, and reloaded with the round trip exposed at every chunk end.
+    auto part_ptr = [&](int c) -> float* {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const size_t row = (size_t)b * p.m_max + min(qt * BQ + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
+        return p.part_o + ((size_t)c * p.batch * p.m_max + row) * (p.heads * D) + head * D;
+    };
+    auto part_lse = [&](int c) -> float* {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const size_t li = ((size_t)b * p.heads + head) * p.m_max + min(qt * BQ + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
+        return p.part_l + (size_t)c * p.batch * p.heads * p.m_max + li;
+    };
+    // end of a key chunk inside the walk (MODE 1 / 3): normalise it, park it (1) or fold it (3), start afresh
+    auto chunk_end = [&](int c) {
+        const float l_c = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;      // undoes the 2^14 of P (carried by l_c) and the scale of V
+        const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
+        if constexpr (MODE == 1 || MODE == 2) {
+            if (q_ok) {
+                float* op = part_ptr(c);
+#pragma unroll
+                for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) =
+                            make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv, oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
+                if (h == 0) *part_lse(c) = lse_c;
+            }
+        } else {
+            float at, ac, lnew;
+            fold_weights(l_tot2, lse_c, &at, &ac, &lnew);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o_tot[0][e] = fold_value(o_tot[0][e], oacc[0][e] * inv, at, ac);
+                o_tot[1][e] = fold_value(o_tot[1][e], oacc[1][e] * inv, at, ac);
+            }
+            l_tot2 = lnew;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+        m_run = -1.0e30f;
+        l_run = 0.f;
+    };
+    // after the last tile: the last chunk normalised in place (oacc), l_tot2 = its log2-sum-exp; MODE 1 / 3 then fold everything
+    // MODE 1: chunk 0 of the parked results is requested before the last tile's P V step (pre / lpre: the registers of the score
+    // tile the soft-max has just consumed) so that its round trip is not exposed at the end of the workgroup
+    float4 pre[2][4];
+    float lpre = 0.f;
+    auto fetch_part = [&](int c, float4 (&v)[2][4], float& l) {
+        const float* op = part_ptr(c);
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[dn][g] = *reinterpret_cast<const float4*>(op + dn * 32 + 8 * g + 4 * h);
+        l = *part_lse(c);
+    };
+    auto finish = [&]() {
+        const float l_c = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;
+        const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oacc[0][e] *= inv; oacc[1][e] *= inv; }
+        if constexpr (MODE == 1) {
+            // the left fold of combine_x3_kernel over the parked chunks 0 .. nc - 2 and the last one (in registers); the next
+            // chunk's values are requested before the current one is folded
+            const int nc = (nkt - 1) / CT + 1;
+            float ot[2][16], lt = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ot[0][e] = 0.f; ot[1][e] = 0.f; }
+            float4 cur[2][4], nxt[2][4];
+            float lcur = lpre, lnxt = 0.f;
+#pragma unroll
+            for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cur[dn][g] = pre[dn][g];
+            for (int c = 0; c + 1 < nc; ++c) {
+                if (c + 2 < nc) fetch_part(c + 1, nxt, lnxt);
+                float at, ac, lnew;
+                fold_weights(lt, lcur, &at, &ac, &lnew);
+#pragma unroll
+                for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        ot[dn][4 * g + 0] = fold_value(ot[dn][4 * g + 0], cur[dn][g].x, at, ac);
+                        ot[dn][4 * g + 1] = fold_value(ot[dn][4 * g + 1], cur[dn][g].y, at, ac);
+                        ot[dn][4 * g + 2] = fold_value(ot[dn][4 * g + 2], cur[dn][g].z, at, ac);
+                        ot[dn][4 * g + 3] = fold_value(ot[dn][4 * g + 3], cur[dn][g].w, at, ac);
+                    }
+                lt = lnew;
+#pragma unroll
+                for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) cur[dn][g] = nxt[dn][g];
+                lcur = lnxt;
+            }
+            float at, ac, lnew;
+            fold_weights(lt, lse_c, &at, &ac, &lnew);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                oacc[0][e] = fold_value(ot[0][e], oacc[0][e], at, ac);
+                oacc[1][e] = fold_value(ot[1][e], oacc[1][e], at, ac);
+            }
+            l_tot2 = lnew;
+        } else if constexpr (MODE == 3) {
+            float at, ac, lnew;
+            fold_weights(l_tot2, lse_c, &at, &ac, &lnew);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                oacc[0][e] = fold_value(o_tot[0][e], oacc[0][e], at, ac);
+                oacc[1][e] = fold_value(o_tot[1][e], oacc[1][e], at, ac);
+            }
+            l_tot2 = lnew;
+        } else {
+            l_tot2 = lse_c;
+        }
+    };
     // softmax(S) of one tile: running max / sum, the probabilities as fp16 (and their residuals when PSPLIT), O rescaled
     auto softmax = [&](f32x16 (&st)[2]) {
         float tmax = st[0][0];
@@ -495,13 +663,14 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         vmma(1, 1, vb);
     };
 
-    // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own
-    gload_k(0);
+    // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own  (tile numbers relative to t0, which is even: the
+    // stage parity of a tile is that of its absolute number)
+    gload_k(t0);
     lstore_k(0);
-    gload_v(0);
-    if (nkt > 1) gload_k(1);
+    gload_v(t0);
+    if (t0 + 1 < nkt) gload_k(t0 + 1);
     lstore_v(0);
-    if (nkt > 1) lstore_k(1);
+    if (t0 + 1 < nkt) lstore_k(1);
     __syncthreads();
     f32x16 sa[2], sb[2];
 #pragma unroll
@@ -522,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     }
     // tile 0's K stage is rewritten (K_2) at the END of the first loop pass, before that pass's barrier: every wave must be done
     // reading K_0 first
-    if (nkt > 2) __syncthreads();
+    if (t0 + 2 < nkt) __syncthreads();
 
     // tile j (not the last): S_{j+1} = K_{j+1} Q^T interleaved with softmax(S_j), then O += V_j P_j; K_{j+2} and V_{j+1} staged
     auto mid = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
@@ -558,7 +727,22 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         if (more_k) lstore_k(j & 1);
         __syncthreads();
     };
-    int j = 0;
+    int j = t0;
+    if constexpr (MODE != 0) {
+        // Whole key chunks that are followed by at least one more tile: eight tiles (the score-tile ping-pong comes back to
+        // sa), then the chunk's end in straight-line code BETWEEN the tile loops — written as a branch inside the tile loop it
+        // made every accumulator a loop-carried phi of two definitions and cost ~100 register copies per tile (+13 % kernel
+        // time).  Its parking stores go out after the tile's staged loads were waited for; the next load wait is a tile away.
+        while (nkt - j > CT) {
+#pragma unroll 1
+            for (int i = 0; i < CT; i += 2) {
+                mid(j + i, sa, sb);
+                mid(j + i + 1, sb, sa);
+            }
+            j += CT;
+            if (wave_active) chunk_end(j / CT - 1);
+        }
+    }
     for (; j + 2 < nkt; j += 2) {
         mid(j, sa, sb);
         mid(j + 1, sb, sa);
@@ -568,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     if (!wave_active) return;
     // last tile: mask the keys beyond klen, soft-max, P V
     auto last = [&](f32x16 (&sc)[2]) {
-        if (klen & (BKV - 1)) {
+        if ((klen & (BKV - 1)) && nkt == nkt_all) {
             const int kbase = (nkt - 1) * BKV;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -578,24 +762,60 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         }
         softmax(sc);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 1) {
+            if (nkt > CT) fetch_part(0, pre, lpre);
+        }
         pv((nkt - 1) & 1);
     };
     if (in_a) last(sa); else last(sb);
+    finish();
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_tot;
     if (q_ok) {
-        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
+        const size_t row = (size_t)b * p.m_max + qrow;
+        const int clast = (nkt - 1) / CT;          // split mode: the workgroup's last chunk is parked like the others
+        float* op = MODE == 2 ? p.part_o + ((size_t)clast * p.batch * p.m_max + row) * (p.heads * D) + head * D
+                              : p.out + row * p.ldo + head * D;
 #pragma unroll
         for (int dn = 0; dn < 2; ++dn)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
-                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
-                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
-            }
-        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + (log2f(l_tot) - P_EXP_SHIFT);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) =
+                    make_float4(oacc[dn][4 * g + 0], oacc[dn][4 * g + 1], oacc[dn][4 * g + 2], oacc[dn][4 * g + 3]);
+        if (h == 0) {
+            const size_t li = ((size_t)b * p.heads + head) * p.m_max + qrow;
+            if (MODE == 2) p.part_l[(size_t)((nkt - 1) / CT) * p.batch * p.heads * p.m_max + li] = l_tot2;
+            else if (p.lse2) p.lse2[li] = l_tot2;
+        }
     }
+}
+
+// Split mode, second step: one wave per (query row, head), one lane per output dim; the left fold over the key chunks of that
+// row in chunk order — fold_weights / fold_value exactly as the fused kernel (MODE 1) applies them.
+__global__ __launch_bounds__(256) void combine_x3_kernel(ArgsX p) {
+    const int lane = threadIdx.x & 63;
+    const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, qrow, head)
+    const long long units = (long long)p.batch * p.m_max * p.heads;
+    if (unit >= units) return;
+    const int head = (int)(unit % p.heads);
+    const long long row = unit / p.heads;                                       // b * m_max + qrow
+    const int b = (int)(row / p.m_max), qrow = (int)(row - (long long)b * p.m_max);
+    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
+    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
+    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
+    if (qrow >= qlen || klen <= 0) return;            // empty key set: the attention kernel wrote the zeros itself
+    const int nchunk = (klen + p.chunk_tiles * BKV - 1) / (p.chunk_tiles * BKV);
+    const size_t li = ((size_t)b * p.heads + head) * p.m_max + qrow;
+    float ot = 0.f, lt = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        const float oc = p.part_o[((size_t)c * p.batch * p.m_max + row) * (p.heads * D) + head * D + lane];
+        const float lc = p.part_l[(size_t)c * p.batch * p.heads * p.m_max + li];
+        float at, ac, lnew;
+        fold_weights(lt, lc, &at, &ac, &lnew);
+        ot = fold_value(ot, oc, at, ac);
+        lt = lnew;
+    }
+    p.out[(size_t)row * p.ldo + head * D + lane] = ot;
+    if (p.lse2 && lane == 0) p.lse2[li] = lt;
 }
 
 // V^T planes for attention_x3_kernel: [seq][head][64 dims][tv positions] fp16, position = 64 * (t / 64) + pos_of_key(t % 64),
@@ -791,14 +1011,71 @@ extern "C" int pram_attention_x3_vt(const void* v_hi, const void* v_lo, int ldv,
     return pram_launch_status("pram_attention_x3_vt");
 }
 
+// fused or split launch (see "Key chunks" above).  The mode never changes the result.  Both park chunk results in the workspace
+// ([chunks][rows][heads * 64] + [chunks][batch][heads][rows] floats) when a sequence has more than one chunk.
+static int g_chunk_tiles = 0;
+static int chunk_tiles() {
+    if (g_chunk_tiles == 0) {
+        const char* e = getenv("PRAM_ATTN_CHUNK_KEYS");
+        int t = e ? atoi(e) / BKV : DEFAULT_CHUNK_TILES;
+        g_chunk_tiles = (t >= 2 && t % 2 == 0) ? t : DEFAULT_CHUNK_TILES;
+    }
+    return g_chunk_tiles;
+}
+static size_t x3_ws_bytes(int batch, int heads, int m_max, int n_max) {
+    const int nchunks = cdiv(n_max, chunk_tiles() * BKV);
+    if (n_max < 1024 || nchunks < 2) return 0;
+    return (size_t)nchunks * batch * m_max * (heads * D + heads) * sizeof(float);
+}
+
+/* Keys per chunk of pram_attention_x3_f32 (a multiple of 128; default 2048, or PRAM_ATTN_CHUNK_KEYS): process-wide, to be set
+   before the first launch — it fixes where every launch folds its partial soft-maxes.  0 keeps the current value; returns it. */
+extern "C" int pram_attention_x3_set_chunk_keys(int keys) {
+    if (keys >= 128 && keys % 128 == 0) g_chunk_tiles = keys / BKV;
+    return chunk_tiles() * BKV;
+}
+
+static int g_split_target = SPLIT_TARGET;
+// workgroup groups a launch is split into along the keys (1 = fused): as many as bring the grid to ~one workgroup per CU, each a
+// whole number of 512-key chunks
+static int x3_split_groups(int batch, int heads, int m_max, int n_max) {
+    if (n_max < 1024) return 1;
+    const long units = (long)batch * heads * cdiv(m_max, BQ);
+    const int nchunks = cdiv(n_max, chunk_tiles() * BKV);
+    const long g = units > 0 ? g_split_target / units : 1;
+    return (int)(g < 2 ? 1 : (g > nchunks ? nchunks : g));
+}
+
+/* Tuning / test knob: under-filled launches of pram_attention_x3_f32 are split along the keys into as many workgroup groups as bring
+   the grid to `workgroups` (default 256 = one per CU; 0 = never split; negative restores the default).  The mode never changes a
+   result bit; returns the previous value. */
+extern "C" int pram_attention_x3_set_split_target(int workgroups) {
+    const int old = g_split_target;
+    g_split_target = workgroups < 0 ? SPLIT_TARGET : workgroups;
+    return old;
+}
+
+extern "C" size_t pram_attention_x3_workspace_bytes(int batch, int heads, int m_max, int n_max) {
+    return x3_ws_bytes(batch, heads, m_max, n_max);
+}
+
+/* > 1 if pram_attention_x3_f32 with a workspace would run this launch in the split mode (that many key groups), else 1. */
+extern "C" int pram_attention_x3_is_split(int batch, int heads, int m_max, int n_max) { return x3_split_groups(batch, heads, m_max, n_max); }
+
+/* MFMA instructions (v_mfma_f32_32x32x16_f16) the kernel pram_attention_x3_f32 launches for n_max keys issues per 64-key tile and
+   32-query wave; a single-product fp16 attention needs 16 (8 for K Q^T, 8 for P V).  40 = three products for the scores, two
+   for P V (probabilities as one fp16); 48 = three and three (below 1024 keys).  bench.py prices its roofline with this. */
+extern "C" int pram_attention_x3_mfma_per_tile(int n_max) { return n_max < 1024 ? 48 : 40; }
+
 /* Split-fp16 flash attention.  q / k: row-major planes written by pram_linear_x3_f32 (value * 16 = hi + lo; ld* in halves,
    16-byte aligned rows and head offsets); vt: the V^T planes of pram_attention_x3_vt for the KEY side ([batch][heads][64][tv],
    tv = n_max rounded up to 64).  kv_shift > 0: keys / values of sequence s come from sequence (s + kv_shift) % batch (cross
-   attention, both directions in one launch). */
+   attention, both directions in one launch).  workspace (may be NULL): pram_attention_x3_workspace_bytes(...) bytes for the
+   split mode of under-filled launches; without it the launch is fused — same bits either way. */
 extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
                                      const void* vt_hi, const void* vt_lo, float* out, int ldo, float* lse2,
                                      const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
-                                     float scale, int kv_shift, void* stream) {
+                                     float scale, int kv_shift, void* workspace, size_t workspace_bytes, void* stream) {
     PRAM_REQUIRE(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out, "pram_attention_x3_f32: null pointer");
     PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "pram_attention_x3_f32: ld of the fp16 planes must be a multiple of 8");
     PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_x3_f32: bad sizes");
@@ -806,16 +1083,49 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     PRAM_REQUIRE(n_max > 0, "pram_attention_x3_f32: empty key set");
     ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
-            scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift, IN_SCALE};
+            scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift, IN_SCALE, 1, 0, chunk_tiles(), nullptr, nullptr};
     static const char* abl = getenv("PRAM_ATTN_ABLATE");
     static const char* v1 = getenv("PRAM_ATTN_V1");
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (!(v1 && v1[0] == '1') && !abl) {
-        if (n_max < 1024) hipLaunchKernelGGL((attention_x3_pipe_kernel<true>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((attention_x3_pipe_kernel<false>), grid, blk, 0, st, p);
+        if (n_max < 1024) {
+            hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0>), grid, blk, 0, st, p);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
+        const size_t need = x3_ws_bytes(batch, heads, m_max, n_max);
+        static const char* force = getenv("PRAM_ATTN_MODE");      // profiling only: 0 = the unchunked kernel (different last bits), 1 / 2 / 3
+        const int fm = force ? atoi(force) : -1;
+        if (fm == 0) {
+            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 0>), grid, blk, 0, st, p);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
+        if (need == 0 && fm != 3) {      // one chunk per sequence: nothing is parked
+            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 1>), grid, blk, 0, st, p);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
+        if (workspace == nullptr || workspace_bytes < need || fm == 3) {      // no workspace: the fused kernel folds in registers (slower, same bits)
+            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 3>), grid, blk, 0, st, p);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
+        const int nchunks = cdiv(n_max, chunk_tiles() * BKV);
+        p.part_o = (float*)workspace;
+        p.part_l = p.part_o + (size_t)nchunks * batch * m_max * heads * D;
+        int groups = x3_split_groups(batch, heads, m_max, n_max);
+        if (fm == 2 && groups < 2) groups = nchunks;
+        if (groups < 2 || fm == 1) {
+            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 1>), grid, blk, 0, st, p);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
+        p.group_tiles = cdiv(nchunks, groups) * p.chunk_tiles;
+        p.nsplit = cdiv(nchunks * p.chunk_tiles, p.group_tiles);
+        hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 2>), dim3(grid.x, p.nsplit), blk, 0, st, p);
+        const long long rows = (long long)batch * m_max * heads;
+        hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
     }
+    // PRAM_ATTN_V1 / PRAM_ATTN_ABLATE (profiling): the non-pipelined kernel — one online soft-max over all keys, so its results
+    // differ from the chunked default in the last bits
     if (n_max < 1024) {
         hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
@@ -844,7 +1154,7 @@ extern "C" int pram_attention_h16t_f32(const void* q16, int ldq, const void* k16
     if (batch == 0 || m_max == 0) return PRAM_OK;
     PRAM_REQUIRE(n_max > 0, "pram_attention_h16t_f32: empty key set");
     ArgsX p{(const _Float16*)q16, nullptr, (const _Float16*)k16, nullptr, (const _Float16*)vt16, nullptr, out, lse2, q_lens, k_lens,
-            ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f};
-    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+            ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f, 1, 0, 0, nullptr, nullptr};
+    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_h16t_f32");
 }

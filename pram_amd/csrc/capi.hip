@@ -12,5 +12,39 @@ void pram_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int pram_hip_version(void) { return 100; }
+extern "C" int pram_hip_version(void) { return 110; }
+
+// ---- status word (include/pram_hip.h, "range guard"): one caller-owned device word per device, ORed into by the kernels
+static unsigned int* g_status[64] = {nullptr};
+
+unsigned int* pram_status_ptr(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    return g_status[dev];
+}
+
+extern "C" int pram_set_status_word(unsigned int* device_word) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        pram_set_error("pram_set_status_word: no current device");
+        return PRAM_E_ARG;
+    }
+    g_status[dev] = device_word;
+    return PRAM_OK;
+}
+
+extern "C" int pram_read_status_word(unsigned int* host_out, int reset, void* stream) {
+    PRAM_REQUIRE(host_out, "pram_read_status_word: null pointer");
+    unsigned int* w = pram_status_ptr();
+    *host_out = 0u;
+    if (!w) return PRAM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(host_out, w, sizeof(unsigned int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return pram_launch_status("pram_read_status_word");
+    if (reset && *host_out) {
+        if (hipMemsetAsync(w, 0, sizeof(unsigned int), st) != hipSuccess) return pram_launch_status("pram_read_status_word");
+    }
+    return PRAM_OK;
+}
 extern "C" const char* pram_last_error(void) { return g_err; }

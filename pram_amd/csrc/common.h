@@ -28,6 +28,19 @@ static inline int pram_launch_status(const char* what) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// The caller-owned status word of the current device (pram_set_status_word), or nullptr.
+unsigned int* pram_status_ptr(void);
+
+// Range guard of the split-fp16 path: a kernel that turns fp32 values into fp16(value * scale) parts tracks the largest
+// |value * scale| it met; 65520 and above round to +-inf in fp16 (a finite result would be garbage, usually NaN), which is
+// reported in the status word instead of silently.  NaN inputs never compare >= and are not flagged: they propagate as NaN,
+// like the reference's fp32 arithmetic.
+__device__ __forceinline__ void x3_range_flag(unsigned int* status, float amax_scaled) {
+    // one atomic per wave at most: the flag is rare, the test is not
+    if (status != nullptr && amax_scaled >= 65520.0f) atomicOr(status, PRAM_STATUS_X3_RANGE);
+}
+
+
 // Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; after the
 // remap consecutive logical ids share an XCD (and therefore its L2).  Placement is used for
 // speed only, never for correctness.

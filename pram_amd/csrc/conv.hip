@@ -21,6 +21,7 @@ struct ConvArgs {
     int batch, h, wd, cin, cout, ks, stride, relu;
     int ho, wo, m, k;
     int tiles_m, tiles_n;
+    unsigned int* status;      // range guard of the split-fp16 path (common.h), or nullptr
 };
 
 // Shared epilogue of the fp32 and fp16 main loops: bias -> BN scale/shift -> residual -> ReLU.
@@ -259,7 +260,9 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
     auto lb = [&](int pp, int kt, int plane) -> uint4 { return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + koff); };
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 64 * pp) < p.cout; };
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, ACT_SCALE, acc);
+    float amax = 0.f;
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, ACT_SCALE, acc, amax);
+    x3_range_flag(p.status, amax);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -333,7 +336,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
     auto bptr = [&](int row, int plane, int kt) -> const _Float16* {
         return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * p.k + koff;
     };
-    mainloop<MI, WM, WN, false, 0, 1>(smem, adv, la, oka, lb, okb, aptr, bptr, p.k / BK, gemmx3::ACT_SCALE, acc);
+    float amax = 0.f;
+    mainloop<MI, WM, WN, false, 0, 1>(smem, adv, la, oka, lb, okb, aptr, bptr, p.k / BK, gemmx3::ACT_SCALE, acc, amax);
+    x3_range_flag(p.status, amax);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -575,6 +580,7 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
     p.wo = (w + 2 * pad - ks) / stride + 1;
     p.m = batch * p.ho * p.wo;
     p.k = ks * ks * cin;
+    p.status = pram_status_ptr();
     int mi, wn;
     gemm::choose_tile(p.m, cout, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;

@@ -431,3 +431,45 @@ extern "C" int pram_row_top2_f32(const float* x, int ld, long long stride, const
                        col_lens, m_max, n_max, largest, v0, v1, i0);
     return pram_launch_status("pram_row_top2_f32");
 }
+
+// ---------------------------------------------------------------- result record + fills (host-side glue of the query pipeline)
+// Fixed-size per-query result record [B][k][6] fp32: x, y, score, landmark id, match index, match score — what the one
+// all-gather of SURVEY.md §8(e) carries.  landmark / matches may be absent (NULL: 0 / -1 and 0); only the first km keypoints
+// of a query went through the matcher (km <= k: the secondary shape of SURVEY.md §8(d) matches the 512 best of 2048).
+__global__ __launch_bounds__(256) void pack_record_kernel(const float* __restrict__ kpts, const float* __restrict__ scores,
+                                                          const int* __restrict__ landmark, const long long* __restrict__ matches0,
+                                                          const float* __restrict__ mscores0, int k, int km, long long total,
+                                                          float* __restrict__ rec) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (b, keypoint)
+    if (i >= total) return;
+    const long long b = i / k;
+    const int j = (int)(i - b * k);
+    float* r = rec + i * 6;
+    r[0] = kpts[i * 2 + 0];
+    r[1] = kpts[i * 2 + 1];
+    r[2] = scores[i];
+    r[3] = landmark ? (float)landmark[i] : 0.f;
+    const bool m = matches0 != nullptr && j < km;
+    r[4] = matches0 ? (m ? (float)matches0[b * km + j] : -1.f) : 0.f;
+    r[5] = m ? mscores0[b * km + j] : 0.f;
+}
+
+extern "C" int pram_pack_record_f32(const float* kpts, const float* scores, const int* landmark, const long long* matches0,
+                                    const float* mscores0, int batch, int k, int km, float* rec, void* stream) {
+    PRAM_REQUIRE(kpts && scores && rec, "pram_pack_record_f32: null pointer");
+    PRAM_REQUIRE((matches0 == nullptr) == (mscores0 == nullptr) && km >= 0 && km <= k, "pram_pack_record_f32: matches and scores go together, km <= k");
+    const long long total = (long long)batch * k;
+    if (total == 0) return PRAM_OK;
+    hipLaunchKernelGGL(pack_record_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kpts, scores,
+                       landmark, matches0, mscores0, k, km, total, rec);
+    return pram_launch_status("pram_pack_record_f32");
+}
+
+/* count 32-bit words at dst <- value (hipMemsetD32Async on the stream): the "zeros / full" initialisations of the host-side
+   glue without a framework kernel. */
+extern "C" int pram_fill_u32(void* dst, unsigned int value, size_t count, void* stream) {
+    if (count == 0) return PRAM_OK;
+    PRAM_REQUIRE(dst, "pram_fill_u32: null pointer");
+    if (hipMemsetD32Async((hipDeviceptr_t)dst, (int)value, count, (hipStream_t)stream) != hipSuccess) return pram_launch_status("pram_fill_u32");
+    return PRAM_OK;
+}

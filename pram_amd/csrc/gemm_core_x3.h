@@ -61,12 +61,27 @@ __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half
     }
 }
 
+// the same, tracking amax = max |x * s| for the range guard (common.h): products of an fmul are canonical, so the maxima are
+// two v_max3_f32 with |.| modifiers per four values
+__device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo, float& amax) {
+    const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#ifndef PRAM_NO_RANGE_GUARD      // A/B builds only (profiles/): what the tracking costs
+    amax = fmaxf(fmaxf(amax, fabsf(x[0])), fabsf(x[1]));
+    amax = fmaxf(fmaxf(amax, fabsf(x[2])), fabsf(x[3]));
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)x[i];
+        lo[i] = (_Float16)(x[i] - (float)hi[i]);
+    }
+}
+
 // ALoad(p, kt) -> raw float4 A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3];  AOk(p, kt) its predicate
 // BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + 64p][kt*32 + (tid%4)*8 ..+7] (fp16); BOk(p, kt) its predicate
 // Adv(kt): wave-uniform loader state, advanced once per chunk (the convolution's tap / channel walk).
 template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
 __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
-                                         float a_scale, f32x16 (&acc)[MI][2]) {
+                                         float a_scale, f32x16 (&acc)[MI][2], float& amax) {
     using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -104,7 +119,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
             float4 v = g.a[p];
             if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             half4 hi, lo;
-            split4(v, a_scale, hi, lo);
+            split4(v, a_scale, hi, lo, amax);      // amax: range guard (common.h), reported by the caller
             const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;
             *reinterpret_cast<half4*>(&s.ah[buf][off]) = hi;
             *reinterpret_cast<half4*>(&s.al[buf][off]) = lo;

@@ -86,7 +86,7 @@ __device__ __forceinline__ void dma_tile(_Float16* lds_hi, _Float16* lds_lo, Row
 //      row is a duplicate whose outputs the epilogue never stores.
 template <int MI, int WM, int WN, bool APLANES, int ABL, int DMA, class Adv, class ALoad, class AOk, class BLoad, class BOk, class APtr, class BPtr>
 __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, APtr& aptr, BPtr& bptr,
-                                         int nk, float a_scale, f32x16 (&acc)[MI][2]) {
+                                         int nk, float a_scale, f32x16 (&acc)[MI][2], float& amax) {
     static_assert(DMA < 2 || APLANES, "A can only travel by DMA when it is already split");
     using C = Cfg<MI, WM, WN>;
     const int tid = threadIdx.x;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
                 float4 v = g.a[p];
                 if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 half4 hi, lo;
-                split4(v, a_scale, hi, lo);
+                split4(v, a_scale, hi, lo, amax);      // amax: range guard (common.h), reported by the caller
                 const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;
                 *reinterpret_cast<half4*>(&s.ah[buf][off]) = hi;
                 *reinterpret_cast<half4*>(&s.al[buf][off]) = lo;

@@ -34,6 +34,8 @@ struct LinArgs {
     // value columns of a q | k | v projection written TRANSPOSED (the V^T planes of attention_x3.hip, key-permuted) instead of
     // row-major: columns >= vt_col0 are vt_heads heads of 64 value dims, rows are sequences of vt_t (% 64 == 0) tokens
     void* vt_hi; void* vt_lo; int vt_col0, vt_heads, vt_t, vt_tv;
+    // range guard of the split-fp16 path (common.h): the device status word of pram_set_status_word, or nullptr
+    unsigned int* status;
 };
 
 __device__ __forceinline__ bool tile_has_rows(const int* __restrict__ lens, int t_pad, int row0, int bm, int m) {
@@ -42,6 +44,15 @@ __device__ __forceinline__ bool tile_has_rows(const int* __restrict__ lens, int 
     for (int s = row0 / t_pad; s * t_pad < rend; ++s)
         if (max(row0, s * t_pad) - s * t_pad < lens[s]) return true;
     return false;
+}
+
+// a row of a (possibly ragged) token matrix that carries data: rows beyond their sequence's length hold whatever the producer
+// left there (ragged producers never write them) and are staged as zeros — deterministic, and invisible to the range guard
+__device__ __forceinline__ bool row_valid(const int* __restrict__ lens, int t_pad, int row, int m) {
+    if (row >= m) return false;
+    if (!lens) return true;
+    const int sq = row / t_pad;
+    return row - sq * t_pad < lens[sq];
 }
 
 // Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
@@ -65,6 +76,17 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
     // sequences that are not part of this call — AdaGML commits the matching descriptors of the pairs stopping at a layer)
     const bool ragged = p.lens != nullptr;
     const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n) && !ragged;
+    float emax = 0.f;       // range guard: largest |value * out16_scale| this lane turned into split planes (valid rows only)
+    // valid rows of a ragged tile: a tile inside one sequence (the rule: t_pad is a multiple of the tile height) has them up to a
+    // row limit; a tile that straddles sequences asks row_valid per row
+    int rlimit = p.m;
+    bool straddle = false;
+    if (ragged) {
+        const int sq = row0 / p.t_pad;
+        if ((min(row0 + BM, p.m) - 1) / p.t_pad == sq) rlimit = min(p.m, sq * p.t_pad + p.lens[sq]);
+        else straddle = true;
+    }
+    auto rvalid = [&](int row) -> bool { return straddle ? row_valid(p.lens, p.t_pad, row, p.m) : row < rlimit; };
 #pragma clang loop unroll(full)      // acc[mi] must stay in registers: a rolled loop would index it dynamically (scratch)
     for (int mi = 0; mi < MI; ++mi) {
         const int rbase = row0 + wm * 32 * MI;
@@ -122,6 +144,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                         const int e = 8 * g + i;
                         const bool ok = t0 + (i & 3) + 8 * (2 * g + (i >> 2)) + 4 * h < len;
                         const float s0 = ok ? q0[e] * p.out16_scale : 0.f, s1 = ok ? q1[e] * p.out16_scale : 0.f;
+                        emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
                         h0[i] = (_Float16)s0;
                         l0[i] = (_Float16)(s0 - (float)h0[i]);
                         h1[i] = (_Float16)s1;
@@ -147,6 +170,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             for (int e = 0; e < 16; ++e) {
                 const int rr = acc_row(0, e, h);
                 const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
+                if (rvalid(rbase + mi * 32 + rr)) emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
                 const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
                 sh[rr * LD + r] = h0;
                 sh[rr * LD + 32 + r] = h1;
@@ -163,8 +187,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                 const int row = rbase + mi * 32 + rr;
                 const half8v vh = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
                 const half8v vl = *reinterpret_cast<const half8v*>(sl + rr * LD + seg * 8);
-                bool ok = row < p.m && cok;
-                if (ragged && ok) { const int sq = row / p.t_pad; ok = row - sq * p.t_pad < p.lens[sq]; }      // as the fp32 output below
+                const bool ok = cok && rvalid(row);      // as the fp32 output below
                 if (ok) {
                     *reinterpret_cast<half8v*>(oh + (size_t)row * p.ldo16 + cbase + seg * 8) = vh;
                     *reinterpret_cast<half8v*>(ol + (size_t)row * p.ldo16 + cbase + seg * 8) = vl;
@@ -177,10 +200,9 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + acc_row(mi, e, h);
-                bool ok = row < p.m;
-                if (ragged && ok) { const int sq = row / p.t_pad; ok = row - sq * p.t_pad < p.lens[sq]; }
-                if (ok) {
+                if (rvalid(row)) {
                     const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
+                    emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
                     const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
                     if (c0ok) { oh[(size_t)row * p.ldo16 + c0] = h0; ol[(size_t)row * p.ldo16 + c0] = (_Float16)(s0 - (float)h0); }
                     if (c1ok) { oh[(size_t)row * p.ldo16 + c1] = h1; ol[(size_t)row * p.ldo16 + c1] = (_Float16)(s1 - (float)h1); }
@@ -209,15 +231,14 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + acc_row(mi, e, h);
-                bool ok = row < p.m;
-                if (ragged && ok) { const int sq = row / p.t_pad; ok = row - sq * p.t_pad < p.lens[sq]; }
-                if (ok) {
+                if (rvalid(row)) {
                     if (c0ok) out[(size_t)row * p.ldo + c0] = q0[e];
                     if (c1ok) out[(size_t)row * p.ldo + c1] = q1[e];
                 }
             }
         }
     }
+    if (p.out16_lo) x3_range_flag(p.status, emax);
 }
 
 template <int MI, int WN, int BKT>
@@ -323,11 +344,13 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
     const int mlast = p.m - 1, nlast = p.n - 1;
     const float* arow0[C::PA];
     const float* arow1[C::PA];
+    unsigned rowok = 0u;
 #pragma unroll
     for (int pp = 0; pp < C::PA; ++pp) {
         const int rc = min(row0 + arow + 32 * pp, mlast);
         arow0[pp] = p.a0 + (size_t)rc * p.lda0;
         arow1[pp] = p.a1 ? p.a1 + (size_t)rc * p.lda1 - p.k0 : arow0[pp];
+        rowok |= (row_valid(p.lens, p.t_pad, row0 + arow + 32 * pp, p.m) ? 1u : 0u) << pp;
     }
     size_t boff[C::PB];
 #pragma unroll
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
         const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
         return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
     };
-    auto oka = [&](int pp, int kt) -> bool { return (row0 + arow + 32 * pp) < p.m && (kt * BK + akq * 4) < K; };
+    auto oka = [&](int pp, int kt) -> bool { return ((rowok >> pp) & 1u) && (kt * BK + akq * 4) < K; };
     auto lb = [&](int pp, int kt, int plane) -> uint4 {
         const int kc = min(kt * BK + bsl * 8, K - 8);
         return *reinterpret_cast<const uint4*>((plane ? wl : wh) + boff[pp] + kc);
@@ -345,7 +368,9 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 64 * pp) < p.n && (kt * BK + bsl * 8) < K; };
     auto adv = [](int) {};
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc);
+    float amax = 0.f;
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax);
+    x3_range_flag(p.status, amax);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -464,24 +489,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             if (k >= p.k0 && p.k1 > 0) return (plane ? a.a1l : a.a1h) + rc * a.lda1 + (k - p.k0);
             return (plane ? a.a0l : a.a0h) + rc * a.lda0 + k;
         };
-        mainloop<MI, WM, WN, true, ABL, (DMA ? 2 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc);
+        float amax = 0.f;      // planes in: nothing is split here
+        mainloop<MI, WM, WN, true, ABL, (DMA ? 2 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);
     } else {
         const float* arow0[C::PA];
         const float* arow1[C::PA];
+        unsigned rowok = 0u;
 #pragma unroll
         for (int pp = 0; pp < C::PA; ++pp) {
             const int rc = min(row0 + arow + C::RA * pp, mlast);
             arow0[pp] = p.a0 + (size_t)rc * p.lda0;
             arow1[pp] = p.a1 ? p.a1 + (size_t)rc * p.lda1 - p.k0 : arow0[pp];
+            rowok |= (row_valid(p.lens, p.t_pad, row0 + arow + C::RA * pp, p.m) ? 1u : 0u) << pp;
         }
         auto la = [&](int pp, int kt) -> float4 {
             const int kc = kt * BK + akq * 4;
             const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 32 == 0
             return *reinterpret_cast<const float4*>((second ? arow1[pp] : arow0[pp]) + kc);
         };
-        auto oka = [&](int pp, int kt) -> bool { return (row0 + arow + C::RA * pp) < p.m; };
+        auto oka = [&](int pp, int kt) -> bool { return ((rowok >> pp) & 1u) != 0u; };
         auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
-        mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc);
+        float amax = 0.f;
+        mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);
+        x3_range_flag(p.status, amax);
     }
     unsigned long long te0 = 0ull;
     if constexpr ((ABL & 4) != 0) te0 = __builtin_readcyclecounter();
@@ -663,6 +693,7 @@ extern "C" int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda
     LinArgs p{nullptr, lda0, k0, nullptr, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
               rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE};
     PlaneArgs a{(const _Float16*)a0_hi, (const _Float16*)a0_lo, lda0, (const _Float16*)a1_hi, (const _Float16*)a1_lo, lda1};
+    p.status = pram_status_ptr();
     int mi, wn;
     gemm::choose_tile(m, n, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
@@ -704,6 +735,7 @@ static int linear_x3_impl(const VtOut* vt, const int* lens, int t_pad, const flo
     LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
               rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE, lens, t_pad};
     PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_x3_f32: lens needs t_pad > 0");
+    p.status = pram_status_ptr();
     if (vt) {
         PRAM_REQUIRE(vt->hi && vt->lo && out_hi && out_lo, "pram_linear_x3_qkv_f32: null pointer");
         PRAM_REQUIRE(vt->t_seq > 0 && vt->t_seq % 64 == 0 && m % vt->t_seq == 0 && (!lens || t_pad == vt->t_seq),

@@ -176,7 +176,12 @@ def with_model_precision(fn):
     @functools.wraps(fn)
     def wrapper(self, *a, **k):
         with ops.precision_scope(getattr(self, "precision", None)):
-            return fn(self, *a, **k)
+            # range guard of the split-fp16 path (ops.guarded_call): a value the format cannot carry re-runs the call on the
+            # exact-fp32 kernels (or raises) instead of coming back as NaN-derived indices
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                return fn(self, *a, **k)      # raises the "no CPU path" error itself
+            return ops.guarded_call(lambda: fn(self, *a, **k), dev)
     return wrapper
 
 

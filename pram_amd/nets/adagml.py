@@ -15,7 +15,7 @@ from torch import nn
 
 from .. import ops
 from . import _blocks as blk
-from .gml import GML, normalize_inputs, sink_algorithm, dual_softmax  # noqa: F401  (API parity)
+from .gml import GML, normalize_inputs, sink_algorithm, dual_softmax, stack_encodings  # noqa: F401  (API parity)
 
 
 class _Pooling(nn.Module):
@@ -147,11 +147,7 @@ class AdaGML(GML):
         dev = desc0.device
         X = torch.zeros(2 * B, T, desc0.shape[2], device=dev, dtype=torch.float32)
         X[:B, :m], X[B:, :n] = desc0, desc1
-        cos = torch.zeros(2 * B, T, 32, device=dev, dtype=torch.float32)
-        sin = torch.zeros(2 * B, T, 32, device=dev, dtype=torch.float32)
-        c0, s0 = ops.fourier_encoding(k0.float(), P["Wr"], cx0, cy0, sc0)
-        c1, s1 = ops.fourier_encoding(k1.float(), P["Wr"], cx1, cy1, sc1)
-        cos[:B, :m], sin[:B, :m], cos[B:, :n], sin[B:, :n] = c0, s0, c1, s1
+        cos, sin = stack_encodings(k0, k1, (cx0, cy0, sc0), (cx1, cy1, sc1), P["Wr"], T)
         ind = torch.zeros(2 * B, T, device=dev, dtype=torch.int32)
         ind[:B, :m] = torch.arange(m, device=dev, dtype=torch.int32)
         ind[B:, :n] = torch.arange(n, device=dev, dtype=torch.int32)

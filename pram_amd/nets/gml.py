@@ -63,23 +63,58 @@ def normalize_inputs(data: dict):
     raise ValueError('Require image shape for keypoint coordinate normalization')
 
 
+_const_cache = {}
+
+
+def _const_i32(device, n: int, value: int) -> torch.Tensor:
+    """A cached [n] int32 device tensor filled with ``value`` (the "every set is full" lengths): no kernel in steady state."""
+    key = (str(device), n, value)
+    t = _const_cache.get(key)
+    if t is None:
+        t = _const_cache[key] = torch.full((n,), value, device=device, dtype=torch.int32)
+    return t
+
+
 def stack_pair(desc0: torch.Tensor, desc1: torch.Tensor, lens0, lens1):
-    """[B,M,D],[B,N,D] -> X [2B, T, D] (T = max(M,N), zero padded) and lens int32 [2B] or None."""
+    """[B,M,D],[B,N,D] -> X [2B, T, D] (T = max(M,N), zero padded) and lens int32 [2B] or None.  Contiguous fp32 inputs of equal
+    size are placed with two device-to-device copies (no framework kernel on the path)."""
     B, M, D = desc0.shape
     N = desc1.shape[1]
     T = max(M, N)
+    dev = desc0.device
     if M == N:
-        X = torch.cat([desc0, desc1], 0).float().contiguous()
+        X = torch.empty(2 * B, T, D, device=dev, dtype=torch.float32)
+        X[:B].copy_(desc0)
+        X[B:].copy_(desc1)
     else:
-        X = torch.zeros(2 * B, T, D, device=desc0.device, dtype=torch.float32)
+        X = ops._filled((2 * B, T, D), dev)
         X[:B, :M] = desc0
         X[B:, :N] = desc1
     lens = None
     if lens0 is not None or lens1 is not None or M != N:
-        l0 = lens0 if lens0 is not None else torch.full((B,), M, device=desc0.device, dtype=torch.int32)
-        l1 = lens1 if lens1 is not None else torch.full((B,), N, device=desc0.device, dtype=torch.int32)
-        lens = torch.cat([l0.int(), l1.int()]).contiguous()
+        lens = torch.empty(2 * B, device=dev, dtype=torch.int32)
+        lens[:B].copy_(lens0 if lens0 is not None else _const_i32(dev, B, M))
+        lens[B:].copy_(lens1 if lens1 is not None else _const_i32(dev, B, N))
     return X, T, lens
+
+
+def stack_encodings(k0, k1, enc0, enc1, Wr, T: int):
+    """Fourier encodings of both keypoint sets as one [2B * T, 32] (cos, sin) pair, rows beyond a set's size zero: the encoder
+    writes straight into its half when the sets are equally large (no copies)."""
+    B, M = k0.shape[0], k0.shape[1]
+    N = k1.shape[1]
+    dev = k0.device
+    if M == N == T:
+        cos = torch.empty(2 * B, T, 32, device=dev, dtype=torch.float32)
+        sin = torch.empty(2 * B, T, 32, device=dev, dtype=torch.float32)
+        ops.fourier_encoding(k0.float(), Wr, *enc0, out=(cos[:B], sin[:B]))
+        ops.fourier_encoding(k1.float(), Wr, *enc1, out=(cos[B:], sin[B:]))
+    else:
+        cos, sin = ops._filled((2 * B, T, 32), dev), ops._filled((2 * B, T, 32), dev)
+        c0, s0 = ops.fourier_encoding(k0.float(), Wr, *enc0)
+        c1, s1 = ops.fourier_encoding(k1.float(), Wr, *enc1)
+        cos[:B, :M], sin[:B, :M], cos[B:, :N], sin[B:, :N] = c0, s0, c1, s1
+    return cos, sin
 
 
 class GML(blk.PackedCache, nn.Module):
@@ -133,12 +168,7 @@ class GML(blk.PackedCache, nn.Module):
         B, M, _ = desc0.shape
         N = desc1.shape[1]
         X, T, lens = stack_pair(desc0, desc1, data.get('lens0'), data.get('lens1'))
-        dev = X.device
-        cos = torch.zeros(2 * B, T, 32, device=dev, dtype=torch.float32)
-        sin = torch.zeros(2 * B, T, 32, device=dev, dtype=torch.float32)
-        c0, s0 = ops.fourier_encoding(k0.float(), P["Wr"], cx0, cy0, sc0)
-        c1, s1 = ops.fourier_encoding(k1.float(), P["Wr"], cx1, cy1, sc1)
-        cos[:B, :M], sin[:B, :M], cos[B:, :N], sin[B:, :N] = c0, s0, c1, s1
+        cos, sin = stack_encodings(k0, k1, (cx0, cy0, sc0), (cx1, cy1, sc1), P["Wr"], T)
         cos, sin = cos.view(-1, 32), sin.view(-1, 32)
         x = ops.linear(X.view(2 * B * T, -1), P["in_w"], P["in_b"])
         nI = self.n_layers
@@ -149,10 +179,11 @@ class GML(blk.PackedCache, nn.Module):
         ldc = (T + 3) // 4 * 4
         if blk._split_path() and d % 32 == 0:
             # the matching descriptors leave the projection as split planes and meet on the fp16 matrix pipe as well
-            _, pl = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, split_out="only")
+            # ragged like everything upstream: rows beyond a set's size hold whatever the (ragged) producers left there
+            _, pl = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, split_out="only", lens=lens, t_pad=T)
             dist = ops.bgemm_nt_planes((pl[0][:B * T], pl[1][:B * T]), (pl[0][B * T:], pl[1][B * T:]), B, T, T, ldc=ldc)
         else:
-            md = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25).view(2 * B, T, d)
+            md = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, lens=lens, t_pad=T).view(2 * B, T, d)
             dist = ops.bgemm_nt(md[:B], md[B:], ldc=ldc)
         r = ops.sinkhorn_match(dist, P["bin"], self.sinkhorn_iterations, p,
                                m_lens=None if lens is None else lens[:B], n_lens=None if lens is None else lens[B:],

@@ -110,12 +110,15 @@ class SegNetViT(blk.PackedCache, nn.Module):
         cos, sin = cos.reshape(B * N, 32), sin.reshape(B * N, 32)
         for lp in P["layers"]:
             x = blk.self_block(x, lp, cos, sin, B, N, lens)
-        h = ops.linear(x, P["seg0_w"], P["seg0_b"])
-        ops.layernorm_gelu_(h, P["seg1_w"], P["seg1_b"])
-        out = ops.linear(h, P["seg3_w"], P["seg3_b"])
+        kw = dict(lens=lens, t_pad=N)      # ragged like the layers: rows beyond a frame's keypoint count are never read or written
+        h = ops.linear(x, P["seg0_w"], P["seg0_b"], **kw)
+        ops.layernorm_gelu_(h, P["seg1_w"], P["seg1_b"], **kw)
+        # the logits of rows beyond a frame's keypoint count read zero (they are the tensor the caller sees), not leftovers
+        o0 = None if lens is None else ops._filled((B * N, P["seg3_w"].shape[0]), x.device)
+        out = ops.linear(h, P["seg3_w"], P["seg3_b"], out=o0, **kw)
         output = {'prediction': out.view(B, N, -1)}
         if self.with_sc:
-            h = ops.linear(x, P["sc0_w"], P["sc0_b"])
-            ops.layernorm_gelu_(h, P["sc1_w"], P["sc1_b"])
-            output['sc'] = ops.linear(h, P["sc3_w"], P["sc3_b"]).view(B, N, 3)
+            h = ops.linear(x, P["sc0_w"], P["sc0_b"], **kw)
+            ops.layernorm_gelu_(h, P["sc1_w"], P["sc1_b"], **kw)
+            output['sc'] = ops.linear(h, P["sc3_w"], P["sc3_b"], **kw).view(B, N, 3)
         return output

@@ -35,6 +35,16 @@ def _rows2d(t: torch.Tensor, name: str) -> Tuple[int, int]:
     return t.numel() // t.shape[-1], t.shape[-1]
 
 
+def _filled(shape, device, dtype=torch.float32, word: int = 0) -> torch.Tensor:
+    """torch.zeros / torch.full for 32-bit dtypes without a framework kernel: torch.empty + hipMemsetD32Async on the current stream
+    (``word`` = the 32-bit pattern; -2 as int32 is 0xFFFFFFFE)."""
+    t = torch.empty(shape, device=device, dtype=dtype)
+    assert t.element_size() == 4
+    if t.numel():
+        _lib.check(_lib.load().pram_fill_u32(t.data_ptr(), word & 0xFFFFFFFF, t.numel(), _st()), "pram_fill_u32")
+    return t
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
            rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, half_copy: str = "no", split_out: str = "no",
@@ -76,7 +86,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         flags = 1
     K = k0 + k1
     use16 = prec == "f16" and K % 64 == 0 and (k1 == 0 or k0 % 64 == 0)
-    usex3 = prec == "x3" and K % 32 == 0 and (k1 == 0 or k0 % 32 == 0)
+    x3_shape = K % 32 == 0 and (k1 == 0 or k0 % 32 == 0)
+    if use16 and lens is not None and half_copy == "no":
+        # The fp16 GEMM has no ragged mode: it would write EVERY row — and ragged callers (AdaGML committing the matching
+        # descriptors of the pairs that stop at a layer into a persistent buffer) rely on untouched rows.  Ragged calls on the
+        # fp16 path therefore run on the split-fp16 kernel (same pipe, three products, honours lens) or, for odd K, on the
+        # exact-fp32 one.
+        use16 = False
+        prec = "x3" if x3_shape else "f32"
+    usex3 = prec == "x3" and x3_shape
     if half_copy != "no":
         if not use16:
             raise _lib.PramHipError("linear(half_copy=...) needs the fp16 GEMM path (precision 'f16', K % 64 == 0)")
@@ -221,14 +239,18 @@ def layernorm_gelu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ep
     return x
 
 
-def fourier_encoding(kpts: torch.Tensor, wr: torch.Tensor, cx: float, cy: float, scale: float):
-    """kpts [..., 2] -> (cos, sin) [..., 32]"""
+def fourier_encoding(kpts: torch.Tensor, wr: torch.Tensor, cx: float, cy: float, scale: float, out=None):
+    """kpts [..., 2] -> (cos, sin) [..., 32]; out: a (cos, sin) pair of contiguous [rows, 32] views to write into."""
     L = _lib.load()
     kpts = kpts.contiguous().float()
     _chk(kpts, "kpts")
     rows = kpts.numel() // 2
-    cos = torch.empty(*kpts.shape[:-1], 32, device=kpts.device, dtype=torch.float32)
-    sin = torch.empty_like(cos)
+    if out is not None:
+        cos, sin = out
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.numel() == rows * 32 and sin.numel() == rows * 32
+    else:
+        cos = torch.empty(*kpts.shape[:-1], 32, device=kpts.device, dtype=torch.float32)
+        sin = torch.empty_like(cos)
     _lib.check(L.pram_fourier_encoding_f32(_p(kpts), _p(wr), float(cx), float(cy), float(scale), _p(cos), _p(sin), rows, _st()),
                "pram_fourier_encoding_f32")
     return cos, sin
@@ -269,6 +291,27 @@ def current_precision() -> str:
     return attention_precision if attention_precision == gemm_precision else f"gemm {gemm_precision} / attention {attention_precision}"
 
 
+_forced_precision = None      # set by forced_precision(): wins over every precision_scope entered inside it
+
+
+class forced_precision:
+    """``with ops.forced_precision("f32"): ...`` — every op and every model inside runs on that MFMA path, whatever the
+    models' own ``.precision`` says (the range guard's fallback run)."""
+
+    def __init__(self, p: str):
+        self.p = _check_precision(p)
+
+    def __enter__(self):
+        global _forced_precision, attention_precision, gemm_precision
+        self.saved = (_forced_precision, attention_precision, gemm_precision)
+        _forced_precision = attention_precision = gemm_precision = self.p
+
+    def __exit__(self, *exc):
+        global _forced_precision, attention_precision, gemm_precision
+        _forced_precision, attention_precision, gemm_precision = self.saved
+        return False
+
+
 class precision_scope:
     """``with ops.precision_scope("x3"): ...`` — what a model with a ``.precision`` attribute wraps its forward in."""
 
@@ -278,13 +321,98 @@ class precision_scope:
     def __enter__(self):
         global attention_precision, gemm_precision
         self.saved = (attention_precision, gemm_precision)
-        if self.p is not None:
-            attention_precision = gemm_precision = _check_precision(self.p)
+        p = _forced_precision or self.p      # the range guard's re-run overrides per-model settings too
+        if p is not None:
+            attention_precision = gemm_precision = _check_precision(p)
 
     def __exit__(self, *exc):
         global attention_precision, gemm_precision
         attention_precision, gemm_precision = self.saved
         return False
+
+
+# ---- range guard of the split-fp16 path (include/pram_hip.h, "range guard").  Every x3 kernel that splits fp32 values reports
+# a finite |value| >= 4094.97 (its hi part would be +-inf in fp16) in a device status word owned here, one per device.  Launches
+# are asynchronous, so the word is read where the host synchronises anyway:
+#   * the model entry points (forward / produce_matches / extract_*: nets/_blocks.with_model_precision) read it after their last
+#     launch and, when it is set, re-run the call on the exact-fp32 kernels (x3_guard = "fallback", the default), raise
+#     (x3_guard = "raise"), or leave it to the caller (x3_guard = "deferred": no synchronisation; ask x3_range_exceeded());
+#   * pipeline.QueryPipeline does the same once per run; bench.py defers it to the end of the timed region and reports it.
+x3_guard = _os.environ.get("PRAM_X3_GUARD", "fallback")
+X3_GUARDS = ("fallback", "raise", "deferred")
+_status_words = {}
+_guard_depth = 0
+
+
+def _x3_status(device) -> torch.Tensor:
+    """The status word of ``device`` (allocated and registered with the library on first use)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    w = _status_words.get(key)
+    if w is None:
+        with torch.cuda.device(key):
+            w = torch.zeros(4, device=torch.device("cuda", key), dtype=torch.int32)
+            _lib.check(_lib.load().pram_set_status_word(w.data_ptr()), "pram_set_status_word")
+        _status_words[key] = w
+    return w
+
+
+def x3_range_exceeded(device=None, reset: bool = True) -> bool:
+    """True if a split-fp16 kernel met a value beyond the format's range since the last reset (synchronises with the device:
+    the kernels that could set the word have to be done)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    w = _x3_status(device)
+    torch.cuda.synchronize(device)
+    hit = bool(int(w[0].item()) & 1)
+    if hit and reset:
+        w.zero_()
+    return hit
+
+
+class guard_scope:
+    """``with ops.guard_scope("deferred"): ...`` — the range-guard policy of the enclosed model calls."""
+
+    def __init__(self, mode: str):
+        if mode not in X3_GUARDS:
+            raise _lib.PramHipError(f"unknown x3 guard {mode!r} (expected one of {X3_GUARDS})")
+        self.mode = mode
+
+    def __enter__(self):
+        global x3_guard
+        self.saved, x3_guard = x3_guard, self.mode
+
+    def __exit__(self, *exc):
+        global x3_guard
+        x3_guard = self.saved
+        return False
+
+
+def guarded_call(fn, device):
+    """Run ``fn()`` (a model entry point) under the range guard: only the OUTERMOST guarded call checks the status word, after
+    its last launch; nothing is checked while a stream is capturing (a hipGraph cannot synchronise: GraphedPipeline checks after
+    the replay) or when neither matrix family runs on the split path."""
+    global _guard_depth
+    outer = _guard_depth == 0
+    _guard_depth += 1
+    try:
+        out = fn()
+    finally:
+        _guard_depth -= 1
+    if not outer or x3_guard == "deferred" or "x3" not in (gemm_precision, attention_precision):
+        return out
+    if x3_guard not in X3_GUARDS:
+        raise _lib.PramHipError(f"unknown x3 guard {x3_guard!r} (expected one of {X3_GUARDS})")
+    if torch.cuda.is_current_stream_capturing() or not x3_range_exceeded(device):
+        return out
+    if x3_guard == "raise":
+        raise _lib.PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 (fp16(16 x) overflows) — re-run with "
+                                "precision 'f32' (or PRAM_X3_GUARD=fallback)")
+    _guard_depth += 1
+    try:
+        with forced_precision("f32"):
+            return fn()
+    finally:
+        _guard_depth -= 1
 
 
 # Derived forms of a (static) weight tensor — its fp16 copy, its split planes — live exactly as long as the tensor object
@@ -322,6 +450,7 @@ def split_weight(w: torch.Tensor):
         hi = ts.half()
         lo = (ts - hi.float()).half()
         return hi.contiguous(), lo.contiguous(), float(scale)
+    _x3_status(w.device)      # every split-fp16 GEMM / convolution comes through here: the range guard's status word is registered
     return _derived(w, "x3", make)
 
 
@@ -366,7 +495,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         e1.record()
         # algorithmic FLOPs of QK^T + PV: 4 * m_b * n_b * 64 per (batch element, head), from the ACTUAL ragged
         # lengths (device tensors, summed by the caller after synchronising)
-        probe.append((q_lens, k_lens, m_max, n_max, heads, batch, e0, e1))
+        probe.append((q_lens, k_lens, m_max, n_max, heads, batch, e0, e1, "self", 16))
     return (out, lse) if want_lse else out
 
 
@@ -401,7 +530,7 @@ def attention_h16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int,
     if probe is not None:
         e1.record()
         kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
-        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1))
+        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1, "cross" if kv_shift else "self", 16))
     return (out, lse) if want_lse else out
 
 
@@ -437,7 +566,7 @@ def attention_h16t(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: in
     if probe is not None:
         e1.record()
         kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
-        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1))
+        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1, "cross" if kv_shift else "self", 16))
     return (out, lse) if want_lse else out
 
 
@@ -473,13 +602,19 @@ def attention_x3(q, k, vt, batch: int, heads: int, m_max: int, n_max: int, scale
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    # from 1024 keys on the kernel parks its key chunks in a workspace; under-filled launches (one or two query frames) run the
+    # chunks as a grid dimension: same bits, shorter serial walk.  attention_split = False (tests): no workspace -> always fused.
+    nb = int(L.pram_attention_x3_workspace_bytes(batch, heads, m_max, n_max)) if attention_split else 0
+    ws = _workspace(nb, q[0].device, "attention_x3") if nb else None
+    _x3_status(q[0].device)
     _lib.check(L.pram_attention_x3_f32(_p(q[0]), _p(q[1]), q[0].stride(0), _p(k[0]), _p(k[1]), k[0].stride(0), _p(vt[0]), _p(vt[1]),
                                        _p(out), out.stride(0), _p(lse), _p(q_lens), _p(k_lens), batch, heads,
-                                       m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_x3_f32")
+                                       m_max, n_max, float(scale), int(kv_shift), _p(ws), nb, _st()), "pram_attention_x3_f32")
     if probe is not None:
         e1.record()
         kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
-        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1))
+        probe.append((q_lens, kl, m_max, n_max, heads, batch, e0, e1, "cross" if kv_shift else "self",
+                      int(L.pram_attention_x3_mfma_per_tile(n_max))))
     return (out, lse) if want_lse else out
 
 
@@ -530,7 +665,7 @@ def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t
     _lib.check(rc, "pram_attention_cross_" + prec)
     if probe is not None:
         e1.record()
-        probe.append((lens, None if lens is None else torch.roll(lens, -pairs), t_max, t_max, heads, S, e0, e1))
+        probe.append((lens, None if lens is None else torch.roll(lens, -pairs), t_max, t_max, heads, S, e0, e1, "cross", 16))
     return (out, lse) if want_lse else out
 
 
@@ -733,9 +868,9 @@ def select_keypoints(nms: torch.Tensor, conf_th: float, min_keypoints: int, bord
     B, H, W = nms.shape
     k = int(max_keypoints)
     ws = _workspace(L.pram_select_keypoints_workspace_bytes(B, H, W, k), nms.device, "select")
-    kpts = torch.zeros(B, k, 2, device=nms.device, dtype=torch.float32)
-    scores = torch.zeros(B, k, device=nms.device, dtype=torch.float32)
-    counts = torch.zeros(B, device=nms.device, dtype=torch.int32)
+    kpts = _filled((B, k, 2), nms.device)
+    scores = _filled((B, k), nms.device)
+    counts = _filled((B,), nms.device, torch.int32)
     _lib.check(L.pram_select_keypoints_f32(_p(nms), B, H, W, float(conf_th), int(min_keypoints), int(border), k,
                                            int(fallback_ref), _p(kpts), _p(scores), _p(counts), _p(ws), _st()),
                "pram_select_keypoints_f32")
@@ -749,7 +884,7 @@ def sample_nhwc(fmap: torch.Tensor, kpts: torch.Tensor, lens: Optional[torch.Ten
     kpts = kpts.contiguous()
     B, fh, fw, Cc = fmap.shape
     N = kpts.shape[1]
-    out = torch.zeros(B, N, Cc, device=fmap.device, dtype=torch.float32)
+    out = _filled((B, N, Cc), fmap.device)
     _lib.check(L.pram_sample_nhwc_f32(_p(fmap), B, fh, fw, Cc, _p(kpts), _p(lens), N, int(s), int(l2norm), _p(out), _st()),
                "pram_sample_nhwc_f32")
     return out
@@ -769,7 +904,7 @@ def score_lookup(score_map_: torch.Tensor, kpts: torch.Tensor, lens: Optional[to
     kpts = kpts.contiguous()
     B, H, W = score_map_.shape
     Bk, N = kpts.shape[0], kpts.shape[1]
-    out = torch.zeros(Bk, N, device=kpts.device, dtype=torch.float32)
+    out = _filled((Bk, N), kpts.device)
     stride = 0 if B == 1 else H * W
     _lib.check(L.pram_score_lookup_f32(_p(score_map_), stride, H, W, _p(kpts), _p(lens), Bk, N, _p(out), _st()),
                "pram_score_lookup_f32")
@@ -795,10 +930,10 @@ def seg_epilogue(logits: torch.Tensor, lens: Optional[torch.Tensor], bg_threshol
     logits = logits.contiguous()
     _chk(logits, "logits")
     B, N, Cc = logits.shape
-    ids = torch.full((B, N), -2, device=logits.device, dtype=torch.int32)
-    mask = torch.zeros(B, N, device=logits.device, dtype=torch.int32)
-    cnt = torch.zeros(B, device=logits.device, dtype=torch.int32)
-    sc = torch.zeros_like(logits) if want_scores else None
+    ids = _filled((B, N), logits.device, torch.int32, -2)
+    mask = _filled((B, N), logits.device, torch.int32)
+    cnt = torch.empty(B, device=logits.device, dtype=torch.int32)      # cleared by the entry itself
+    sc = _filled(tuple(logits.shape), logits.device) if want_scores else None
     _lib.check(L.pram_seg_epilogue_f32(_p(logits), _p(lens), B, N, Cc, float(bg_threshold), _p(sc), _p(ids), _p(mask), _p(cnt), _st()),
                "pram_seg_epilogue_f32")
     return ids, mask, cnt, sc
@@ -893,3 +1028,25 @@ def seg_vote(sorted_vals: torch.Tensor, sorted_ids: torch.Tensor, topk: int):
     _lib.check(L.pram_seg_vote(_p(sorted_ids), _p(sorted_vals), n, c, int(topk), _p(sid), _p(rank), _p(cnt), _p(nwin), _p(tokens), _p(mean),
                                _st()), "pram_seg_vote")
     return sid, rank, cnt, nwin, tokens, mean
+
+
+def pack_record(kpts: torch.Tensor, scores: torch.Tensor, landmark: Optional[torch.Tensor] = None,
+                matches0: Optional[torch.Tensor] = None, mscores0: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> [B, k, 6] fp32: x, y, score, landmark id, match index, match score (pram_pack_record_f32); matches0 / mscores0 may cover
+    only the first km <= k keypoints of every query."""
+    L = _lib.load()
+    kpts, scores = kpts.contiguous(), scores.contiguous()
+    _chk(kpts, "kpts"), _chk(scores, "scores")
+    B, k = scores.shape
+    km = 0
+    if matches0 is not None:
+        matches0, mscores0 = matches0.contiguous(), mscores0.contiguous()
+        assert matches0.dtype == _INT64 and mscores0.dtype == torch.float32 and matches0.shape == mscores0.shape
+        km = matches0.shape[1]
+    if landmark is not None:
+        landmark = landmark.contiguous()
+        assert landmark.dtype == torch.int32
+    rec = torch.empty(B, k, 6, device=scores.device, dtype=torch.float32)
+    _lib.check(L.pram_pack_record_f32(_p(kpts), _p(scores), _p(landmark), _p(matches0), _p(mscores0), B, k, km, _p(rec), _st()),
+               "pram_pack_record_f32")
+    return rec

@@ -23,18 +23,31 @@ from . import ops
 
 
 class QueryPipeline:
+    """guard: range guard of the split-fp16 path for one run() (ops.guarded_call): "fallback" (default) reads the device status
+    word once after the last launch — the one host synchronisation of a run — and re-runs the batch on the exact-fp32 kernels
+    when an activation left the fp16 parts' range; "raise" raises instead; "deferred" never synchronises (batches in flight,
+    hipGraph capture): the caller asks ``ops.x3_range_exceeded()`` when it reads the results.
+    match_keypoints: only the first (= best-scoring) M keypoints of every query enter the matcher (SURVEY.md §8(d)'s secondary
+    shape: the keypoints voted to one landmark, localization/multimap3d.py:131-139); 0 = all."""
+
     def __init__(self, sfd2, segnet, matcher, max_keypoints: int = 2048, min_keypoints: int = 128, bg_threshold: float = 0.95,
-                 overlap_below: int = 8):
+                 overlap_below: int = 8, guard: str = "fallback", match_keypoints: int = 0):
         self.sfd2, self.segnet, self.matcher = sfd2, segnet, matcher
         self.bg_threshold = bg_threshold
         self.cfg = {'min_keypoints': min_keypoints, 'max_keypoints': max_keypoints}
         self.overlap_below = overlap_below      # batches smaller than this run recognise || match on two streams
+        self.guard = guard
+        self.match_keypoints = int(match_keypoints)
         self._side = None
 
     def _match(self, ex, ref, W, H):
-        kpts, scores, counts = ex['keypoints'], ex['scores'], ex['counts']
+        kpts, scores, counts, desc = ex['keypoints'], ex['scores'], ex['counts'], ex['descriptors']
+        km = self.match_keypoints
+        if 0 < km < kpts.shape[1]:
+            kpts, scores, desc = kpts[:, :km].contiguous(), scores[:, :km].contiguous(), desc[:, :km].contiguous()
+            counts = torch.clamp(counts, max=km)
         data = {
-            'descriptors0': ex['descriptors'], 'keypoints0': kpts, 'scores0': scores, 'lens0': counts,
+            'descriptors0': desc, 'keypoints0': kpts, 'scores0': scores, 'lens0': counts,
             # the reference hands the matcher (1, 3, width, height) (singlemap3d.py:147,152)
             'image_shape0': (1, 3, W, H),
             'descriptors1': ref['descriptors'], 'keypoints1': ref['keypoints'], 'scores1': ref['scores'],
@@ -45,10 +58,15 @@ class QueryPipeline:
         return self.matcher.produce_matches(data) if hasattr(self.matcher, 'produce_matches') else self.matcher(data)
 
     @torch.no_grad()
-    def run(self, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm") -> Dict[str, torch.Tensor]:
+    def run(self, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm",
+            guard: Optional[str] = None) -> Dict[str, torch.Tensor]:
         """images [B,3,H,W] normalised fp32 on the GPU.  ref: reference-frame sets to match against
         (descriptors [B,Nr,128], keypoints [B,Nr,2], scores [B,Nr], optional lens int32 [B]).
-        stages: any of 'e' (extract), 'r' (recognise), 'm' (match)."""
+        stages: any of 'e' (extract), 'r' (recognise), 'm' (match).  guard: see the class docstring (None = self.guard)."""
+        with ops.guard_scope(guard or self.guard):
+            return ops.guarded_call(lambda: self._run(images, ref, stages), images.device)
+
+    def _run(self, images, ref, stages):
         B, _, H, W = images.shape
         ex = self.sfd2.extract_batched(images, self.cfg, per_image_fallback=True)
         kpts, scores, counts = ex['keypoints'], ex['scores'], ex['counts']
@@ -83,17 +101,9 @@ class QueryPipeline:
 
     @staticmethod
     def pack_record(out: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """Fixed-size per-query record [B, k, 6] fp32: x, y, score, landmark id, match index, match score."""
-        B, k = out['scores'].shape
-        rec = torch.zeros(B, k, 6, device=out['scores'].device, dtype=torch.float32)
-        rec[:, :, 0:2] = out['keypoints']
-        rec[:, :, 2] = out['scores']
-        if out.get('landmark') is not None:
-            rec[:, :, 3] = out['landmark'].float()
-        if 'matches0' in out:
-            rec[:, :, 4] = out['matches0'].float()
-            rec[:, :, 5] = out['matching_scores0']
-        return rec
+        """Fixed-size per-query record [B, k, 6] fp32: x, y, score, landmark id, match index, match score (one kernel,
+        pram_pack_record_f32; keypoints beyond the matcher's share carry match index -1)."""
+        return ops.pack_record(out['keypoints'], out['scores'], out.get('landmark'), out.get('matches0'), out.get('matching_scores0'))
 
 
 def gather_records(rec: torch.Tensor, shard_sizes=None) -> torch.Tensor:
@@ -145,13 +155,18 @@ class GraphedPipeline:
     GPU time does not change (the step is GPU-bound); what changes is the host: ~3 ms of Python / ctypes launches per
     step become one graph launch, which is what matters when the host thread is also solving poses or feeding
     several GPUs.  Inputs are copied into the captured buffers; outputs are the captured tensors (valid until the next
-    replay — clone what must outlive it)."""
+    replay — clone what must outlive it).  ``record=True`` also captures the result record (``self.record``).
+    Range guard: a capture cannot synchronise, so the captured run is "deferred"; ``run()`` reads the status word after the replay
+    (``guard`` = the pipeline's policy) and re-runs eagerly on the exact-fp32 kernels when it is set; ``replay()`` is the bare
+    re-issue for callers that keep several steps in flight and check ``ops.x3_range_exceeded()`` themselves."""
 
     def __init__(self, pipe: QueryPipeline, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm",
-                 warmup: int = 2):
+                 warmup: int = 2, record: bool = False):
         self.pipe, self.stages = pipe, stages
         self.images = images.clone()
         self.ref = None if ref is None else {k: v.clone() for k, v in ref.items()}
+        self.with_record = record
+        self.record = None
         self._ws = {}                 # this graph's private scratch (ops.workspace_scope): never shared, never regrown by others
         self._side = torch.cuda.Stream(device=images.device) if pipe.overlap_below > images.shape[0] else None
         side = torch.cuda.Stream(device=images.device)
@@ -170,9 +185,18 @@ class GraphedPipeline:
         # the forked branch runs on a side stream owned by THIS graph (the pipeline's own side stream keeps serving eager runs)
         saved, self.pipe._side = self.pipe._side, self._side
         try:
-            return self.pipe.run(self.images, self.ref, self.stages)
+            out = self.pipe.run(self.images, self.ref, self.stages, guard="deferred")
+            if self.with_record:
+                self.record = QueryPipeline.pack_record(out)
+            return out
         finally:
             self._side, self.pipe._side = self.pipe._side, saved
+
+    def replay(self) -> Dict[str, torch.Tensor]:
+        """Re-issue the captured step on the current stream with the inputs already in the captured buffers; no synchronisation,
+        no range-guard check."""
+        self.graph.replay()
+        return self.out
 
     @torch.no_grad()
     def run(self, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
@@ -189,4 +213,11 @@ class GraphedPipeline:
             for k, v in ref.items():
                 self.ref[k].copy_(v)
         self.graph.replay()
+        guard = self.pipe.guard
+        if guard != "deferred" and "x3" in (ops.gemm_precision, ops.attention_precision) and ops.x3_range_exceeded(images.device):
+            if guard == "raise":
+                from ._lib import PramHipError
+                raise PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 in the replayed step")
+            with ops.forced_precision("f32"):
+                return self.pipe.run(images, ref, self.stages, guard="deferred")
         return self.out

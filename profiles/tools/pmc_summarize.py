@@ -44,12 +44,17 @@ with open(os.path.join(root, "profiles", f"{tag}_pmc_summary.md"), "w") as o:
                 f"{2 * r['fetch_kb'] / 1024:.1f} | {r['write_kb']:.0f} | {(2 * r['fetch_kb'] + r['write_kb']) * 1024 / (r['avg_us'] * 1e3):.0f} | {r['lds']:.2f} | {r['wait']:.2f} |\n")
 # bench.py reads roofline.traffic from profiles/pmc_attention.json, keyed by the precision of the run (argv[3], default x3)
 prec = sys.argv[3] if len(sys.argv) > 3 else "x3"
-name = {"f32": "attention_kernel", "x3": "attention_x3_pipe_kernel", "f16": "attention_h16_kernel"}[prec]
+name = {"f32": "attention_kernel", "x3": "attention_x3_pipe_kernel", "f16": "attention_x3_pipe_kernel"}[prec]
 att = next((r for r in rows if r["kernel"].startswith(name)), None)
 if att:
     path = os.path.join(root, "profiles", "pmc_attention.json")
     js = json.load(open(path)) if os.path.exists(path) else {}
-    js[prec] = {"kernel": name, "source": f"profiles/{tag}_pmc_summary.md", "hbm_bytes_per_launch": (2 * att["fetch_kb"] + att["write_kb"]) * 1024,
+    import hashlib
+    src = {"x3": "attention_x3.hip", "f32": "attention.hip", "f16": "attention_x3.hip"}[prec]
+    sha = hashlib.sha256(open(os.path.join(root, "pram_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+    # bench.py prints roofline.traffic only while the kernel source it runs hashes to this value: a stale counter is never reported
+    js[prec] = {"kernel": name, "source": f"profiles/{tag}_pmc_summary.md", "kernel_source": f"pram_amd/csrc/{src}", "kernel_source_sha16": sha,
+                "hbm_bytes_per_launch": (2 * att["fetch_kb"] + att["write_kb"]) * 1024,
                 "fetch_size_kb": att["fetch_kb"], "write_size_kb": att["write_kb"], "mfma_util_pct": att["mfma"], "launches": att["launches"]}
     json.dump(js, open(path, "w"), indent=1)
     print(json.dumps(js[prec]))

@@ -1,4 +1,5 @@
-"""Timing of attention_x3 at the bench's launch shapes (warm), optionally under PRAM_ATTN_ABLATE (see attention_x3.hip).
+"""Timing of attention_x3 at the bench's launch shapes (warm), optionally under PRAM_ATTN_ABLATE / PRAM_ATTN_MODE (see
+attention_x3.hip: MODE 0 = the unchunked kernel, 1 = fused with parked key chunks, 2 = split, 3 = fused with the fold in registers).
     python profiles/tools/x3_attn_probe.py"""
 import os
 import sys
@@ -18,7 +19,7 @@ def planes(t):
     return hi.contiguous(), (s - hi.float()).half().contiguous()
 
 
-for B, N in ((16, 2048), (32, 2048), (8, 4096), (1, 2048)):
+for B, N in ((16, 2048), (32, 2048), (8, 4096), (1, 2048), (2, 2048)):
     q = torch.randn(B * N, 256, device=dev)
     k = torch.randn(B * N, 256, device=dev)
     v = torch.randn(B * N, 256, device=dev)
@@ -36,4 +37,4 @@ for B, N in ((16, 2048), (32, 2048), (8, 4096), (1, 2048)):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     fl = 4.0 * B * 4 * N * N * 64
-    print(f"ablate={os.environ.get('PRAM_ATTN_ABLATE', '0')} B={B:3d} N={N}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic ({fl * 2.5 / us / 1e6:7.1f} executed)")
+    print(f"mode={os.environ.get('PRAM_ATTN_MODE', 'auto')} ablate={os.environ.get('PRAM_ATTN_ABLATE', '0')} B={B:3d} N={N}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic ({fl * 2.5 / us / 1e6:7.1f} executed)")

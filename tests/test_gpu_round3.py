@@ -1,0 +1,359 @@
+"""GPU (MI355X): round-3 additions — the range guard of the split-fp16 path, the key-split mode of the split-fp16 attention,
+ragged GEMMs on the fp16 path (AdaGML), the result-record kernel, RCCL with one rank, the secondary matcher shape."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from pram_amd import ops, weights as W
+from pram_amd._lib import PramHipError
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _to(data, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+
+
+# ------------------------------------------------------------------------------------------------ range guard
+def test_range_guard_flags_gemm_operands_and_plane_outputs(dev):
+    """fp16(16 x) overflows for a finite |x| >= 4094.97: the staging of the split-fp16 GEMM and its plane-writing epilogue report
+    it in the status word; in-range values, NaN inputs (which propagate as NaN like the reference's fp32 arithmetic) and the
+    exact-fp32 kernels do not."""
+    w = W.normal(3, "rg/w", (256, 256), 0.05).to(dev)
+    x = W.normal(3, "rg/x", (512, 256), 1.0).to(dev)
+    ops.x3_range_exceeded(dev)                                     # clear
+    y = ops.linear(x, w, precision="x3")
+    assert not ops.x3_range_exceeded(dev) and bool(torch.isfinite(y).all())
+    xb = x.clone()
+    xb[137, 19] = 4094.0                                           # 16 x = 65504: the largest fp16, still fine
+    y = ops.linear(xb, w, precision="x3")
+    assert not ops.x3_range_exceeded(dev) and bool(torch.isfinite(y).all())
+    xb[137, 19] = 4095.0                                           # 16 x = 65520 rounds to +inf
+    y = ops.linear(xb, w, precision="x3")
+    assert ops.x3_range_exceeded(dev)                              # reports and resets
+    assert not ops.x3_range_exceeded(dev)
+    assert not bool(torch.isfinite(y[137]).all())                  # what the caller would otherwise have got: NaN in that row
+    y32 = ops.linear(xb, w, precision="f32")
+    assert bool(torch.isfinite(y32).all()) and not ops.x3_range_exceeded(dev)
+    xn = x.clone()
+    xn[5, 5] = float("nan")
+    y = ops.linear(xn, w, precision="x3")
+    assert not ops.x3_range_exceeded(dev) and bool(torch.isnan(y[5]).all()) and bool(torch.isfinite(y[6]).all())
+    xi = x.clone()
+    xi[9, 0] = float("inf")
+    ops.linear(xi, w, precision="x3")
+    assert ops.x3_range_exceeded(dev)
+    # plane-writing epilogue: in-range operands, out-of-range RESULT (alpha pushes it past 4094.97)
+    _, pl = ops.linear(x, w, alpha=3.0e4, split_out="only", precision="x3")
+    assert ops.x3_range_exceeded(dev)
+    _, pl = ops.linear(x, w, alpha=1.0, split_out="only", precision="x3")
+    assert not ops.x3_range_exceeded(dev)
+    # convolution staging
+    img = W.normal(4, "rg/img", (1, 24, 32, 64), 1.0).to(dev)
+    wc = W.normal(4, "rg/wc", (64, 3, 3, 64), 0.05).to(dev)
+    ops.conv2d_nhwc(img, wc, precision="x3")
+    assert not ops.x3_range_exceeded(dev)
+    img[0, 3, 3, 3] = -5.0e3
+    ops.conv2d_nhwc(img, wc, precision="x3")
+    assert ops.x3_range_exceeded(dev)
+
+
+def _hot_segnet(dev, gain):
+    from pram_amd.nets.load_segnet import load_segnet
+    sd = dict(H.segnet_sd())
+    sd["input_proj.weight"] = sd["input_proj.weight"] * gain        # residual stream O(gain): no normalisation on it (segnetvit.py:105-106)
+    sd["input_proj.bias"] = sd["input_proj.bias"] * gain
+    m = load_segnet('segnetvit', 113, 256, 15, 1024)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def test_range_guard_falls_back_to_exact_fp32_on_a_hot_residual_stream(dev):
+    """A SegNetViT whose residual stream leaves the split format's range: the default policy re-runs the forward on the exact-fp32
+    kernels (result = the f32 path's, finite, close to the oracle); "raise" raises; "deferred" hands the NaN-derived output back
+    with the flag set — never a silently wrong result."""
+    net, sd = _hot_segnet(dev, 6.0e3)
+    N = 192
+    desc = (W.normal(11, "rg/d", (1, N, 256), 0.05)).to(dev)
+    kp = torch.stack([torch.floor(W.uniform(11, "rg/x", (N,), 4.0, 636.0)), torch.floor(W.uniform(11, "rg/y", (N,), 4.0, 476.0))], -1)[None].to(dev)
+    data = {"seg_descriptors": desc, "keypoints": kp, "image": torch.empty(1, 3, 480, 640)}
+    ops.x3_range_exceeded(dev)
+    with ops.guard_scope("deferred"):
+        raw = net.set_precision("x3")(data)["prediction"]
+    assert ops.x3_range_exceeded(dev, reset=True), "fixture must leave the range (else the test proves nothing)"
+    assert not bool(torch.isfinite(raw).all())
+    with ops.guard_scope("raise"):
+        with pytest.raises(PramHipError):
+            net(data)
+    with ops.guard_scope("fallback"):
+        got = net(data)["prediction"]
+    ref32 = net.set_precision("f32")(data)["prediction"]
+    net.set_precision(None)
+    assert bool(torch.isfinite(got).all()) and torch.equal(got, ref32)
+    o = R.segnetvit_forward(sd, desc.cpu(), kp.cpu(), (1, 3, 480, 640))
+    rel = float((got.cpu() - o).abs().max() / o.abs().max())
+    assert rel < 1e-4, rel
+    # an in-range model is untouched by the guard (same bits as with the guard off)
+    net2, _ = _hot_segnet(dev, 1.0)
+    with ops.guard_scope("deferred"):
+        a = net2(data)["prediction"]
+    with ops.guard_scope("fallback"):
+        b = net2(data)["prediction"]
+    assert torch.equal(a, b) and not ops.x3_range_exceeded(dev)
+
+
+def test_nan_and_inf_inputs_behave_like_the_reference(dev):
+    """NaN / Inf in the descriptors: the reference's fp32 arithmetic spreads non-finite values over the whole output (attention
+    mixes every token into every other); so does this path, through whichever kernels the guard picks — never finite garbage."""
+    net, sd = _hot_segnet(dev, 1.0)
+    N = 128
+    desc = W.normal(12, "nn/d", (1, N, 256), 0.05)
+    kp = torch.stack([torch.floor(W.uniform(12, "nn/x", (N,), 4.0, 636.0)), torch.floor(W.uniform(12, "nn/y", (N,), 4.0, 476.0))], -1)[None]
+    for bad in (float("nan"), float("inf")):
+        d = desc.clone()
+        d[0, 7, 3] = bad
+        o = R.segnetvit_forward(sd, d, kp, (1, 3, 480, 640))
+        got = net({"seg_descriptors": d.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"].cpu()
+        assert not bool(torch.isfinite(o).any()) and not bool(torch.isfinite(got).any()), bad
+    ops.x3_range_exceeded(dev)
+
+
+def test_pipeline_guard_and_graph_replay(dev):
+    """QueryPipeline reads the guard once per run; a replayed hipGraph checks after the replay and re-runs eagerly in fp32."""
+    from pram_amd.nets.gml import GML
+    from pram_amd.nets.sfd2 import ResNet4x
+    from pram_amd.pipeline import GraphedPipeline, QueryPipeline
+    sfd2 = ResNet4x()
+    sfd2.load_state_dict(H.sfd2_sd(), strict=True)
+    seg, _ = _hot_segnet(dev, 6.0e3)
+    pipe = QueryPipeline(sfd2.to(dev).eval(), seg, None, max_keypoints=128, min_keypoints=8)
+    img = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)]).to(dev)
+    ops.x3_range_exceeded(dev)
+    out = pipe.run(img, None, stages="er")
+    n = int(out["counts"][0])
+    assert bool(torch.isfinite(out["prediction"][0, :n]).all()) and not ops.x3_range_exceeded(dev)
+    with ops.forced_precision("f32"):
+        want = pipe.run(img, None, stages="er")["prediction"]
+    assert torch.equal(out["prediction"], want)
+    with pytest.raises(PramHipError):
+        pipe.run(img, None, stages="er", guard="raise")
+    raw = pipe.run(img, None, stages="er", guard="deferred")
+    assert ops.x3_range_exceeded(dev) and not bool(torch.isfinite(raw["prediction"][0, :n]).all())
+    g = GraphedPipeline(pipe, img, None, stages="er")
+    ops.x3_range_exceeded(dev)
+    got = g.run(img)
+    assert torch.equal(got["prediction"], want) and not ops.x3_range_exceeded(dev)
+
+
+# ------------------------------------------------------------------------------------------------ key-split attention
+@pytest.fixture
+def chunk_keys():
+    """Sets the process-wide key-chunk size of the split-fp16 attention for one test and restores the default afterwards."""
+    L = ops._lib.load()
+    default = L.pram_attention_x3_set_chunk_keys(0)
+
+    def set_(keys):
+        assert L.pram_attention_x3_set_chunk_keys(keys) == keys
+    yield set_
+    L.pram_attention_x3_set_chunk_keys(default)
+
+
+@pytest.mark.parametrize("shape", [(1, 2048, 2048, 512), (2, 1500, 1100, 512), (1, 2048, 2048, 1024), (1, 1024, 4096, 2048), (3, 640, 1030, 512),
+                                   (1, 2048, 4096, 1024)])
+def test_attention_x3_split_equals_fused(dev, shape, chunk_keys):
+    """Under-filled launches run groups of key chunks as a second grid dimension + a fold kernel; fused launches park the same
+    chunks and fold them at the end (or, without a workspace, in registers): bit-identical outputs and log-sum-exps (so a padded
+    batch element still equals its B = 1 run), at every chunk size."""
+    S, M, N, ck = shape
+    chunk_keys(ck)
+    T = max(M, N)
+    Tp = (T + 63) // 64 * 64
+    x = W.normal(31, f"sp/x{S}{M}{N}", (S * Tp, 256), 1.0).to(dev)
+    wq = W.normal(31, "sp/w", (768, 256), 0.06).to(dev)
+    ql = torch.tensor([M - 17 * i for i in range(S)], dtype=torch.int32, device=dev)
+    kl = torch.tensor([N - 29 * i for i in range(S)], dtype=torch.int32, device=dev)
+    lens = torch.maximum(ql, kl)
+    pl, vt = ops.linear_qkv_planes(x, wq, None, 4, Tp, lens=lens)
+    q3, k3 = (pl[0][:, :256], pl[1][:, :256]), (pl[0][:, 256:512], pl[1][:, 256:512])
+    L = ops._lib.load()
+    assert L.pram_attention_x3_is_split(S, 4, Tp, Tp) > 1, "shape must qualify for the split mode"
+    saved = ops.attention_split
+    try:
+        ops.attention_split = True
+        o1, l1 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # split: chunks as a grid dimension
+        L.pram_attention_x3_set_split_target(0)
+        o2, l2 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # fused, chunks parked in the workspace
+        ops.attention_split = False
+        o3, l3 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # fused, no workspace
+    finally:
+        ops.attention_split = saved
+        L.pram_attention_x3_set_split_target(-1)
+    for s in range(S):
+        m = int(ql[s])
+        for o, l in ((o2, l2), (o3, l3)):
+            assert torch.equal(o1[s * Tp:s * Tp + m], o[s * Tp:s * Tp + m]), s
+            assert torch.equal(l1[s, :, :m], l[s, :, :m]), s
+    # values: against fp64 soft-max attention on the same (split) operands, V recovered from the row-major value planes of an
+    # ordinary projection call
+    _, plv = ops.linear(x, wq, None, split_out="only", lens=lens, t_pad=Tp)
+    full = (plv[0].double() + plv[1].double()) / 16
+    for s in range(S):
+        m, n = int(ql[s]), int(kl[s])
+        qq = full[s * Tp:s * Tp + m, :256].view(m, 4, 64).transpose(0, 1)
+        kk = full[s * Tp:s * Tp + n, 256:512].view(n, 4, 64).transpose(0, 1)
+        vv = full[s * Tp:s * Tp + n, 512:].view(n, 4, 64).transpose(0, 1)
+        want = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(m, 256)
+        d = float((o1[s * Tp:s * Tp + m].double() - want).abs().max())
+        assert d < 2e-4, (s, d)
+
+
+@pytest.mark.parametrize("ck", [512, 2048])
+def test_batched_matcher_equals_b1_with_split_attention(dev, chunk_keys, ck):
+    """GML on 2048-keypoint sets: a batch of 5 pairs (fused attention launches) gives every pair exactly the bits of its own B = 1
+    call (split attention launches with 512-key chunks; one chunk per sequence at the default 2048)."""
+    from pram_amd.nets.gml import GML
+    chunk_keys(ck)
+    net = GML({})
+    net.load_state_dict(H.gml_sd(), strict=True)
+    net = net.to(dev).eval()
+    ds = [H.pair_data(i, 2048, 2048, device=dev)[0] for i in (1, 2, 3, 4, 5)]
+    cat = {k: torch.cat([d[k] for d in ds], 0) for k in ds[0] if torch.is_tensor(ds[0][k])}
+    cat["image_shape0"] = cat["image_shape1"] = (1, 3, 640, 480)
+    rb = net.produce_matches(cat, p=0.0)
+    for i, d in enumerate(ds):
+        r1 = net.produce_matches(d, p=0.0)
+        assert torch.equal(rb["matches0"][i], r1["matches0"][0]) and torch.equal(rb["matching_scores0"][i], r1["matching_scores0"][0]), i
+
+
+# ------------------------------------------------------------------------------------------------ ragged GEMM on the fp16 path
+def test_adagml_fp16_path_commits_only_the_stopping_pairs(dev):
+    """AdaGML under precision 'f16': pairs stop at different layers and their matching descriptors are committed by a RAGGED
+    GEMM into a persistent buffer.  The fp16 GEMM has no ragged mode (it would overwrite the rows of pairs that stopped
+    earlier with projections of stale tokens), so ragged calls run on a kernel that honours lens: the batched call equals the
+    B = 1 calls pair by pair, and agrees with the default path on (almost) all matches."""
+    from pram_amd.nets.adagml import AdaGML
+    sd = dict(H.adagml_sd())
+    for k in list(sd):
+        if k.endswith("predict.3.bias"):
+            sd[k] = sd[k] + 0.08                                   # pairs clear check_if_stop before the last layer
+    net = AdaGML({})
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    ds = [H.pair_data(i, 448, 448, device=dev)[0] for i in (1, 2, 3, 4)]
+    cat = {k: torch.cat([d[k] for d in ds], 0) for k in ds[0] if torch.is_tensor(ds[0][k])}
+    cat["image_shape0"] = cat["image_shape1"] = (1, 3, 640, 480)
+    px = {}
+    rx = net.set_precision("x3").produce_matches(cat, p=0.0, probes=px)
+    pb = {}
+    rb = net.set_precision("f16").produce_matches(cat, p=0.0, probes=pb)
+    stops = [int(s) for s in pb["stop_layer"]]
+    print("adagml f16 stop layers", stops, "x3", [int(s) for s in px["stop_layer"]])
+    assert len(set(stops)) > 1, "fixture should stop the pairs at different layers"
+    for i, d in enumerate(ds):
+        p1 = {}
+        r1 = net.produce_matches(d, p=0.0, probes=p1)
+        assert int(p1["stop_layer"][0]) == stops[i]
+        assert torch.equal(rb["matches0"][i], r1["matches0"][0]), i
+        assert H.maxdiff(rb["matching_scores0"][i], r1["matching_scores0"][0]) == 0.0
+    same = float((rb["matches0"] == rx["matches0"]).float().mean())
+    assert same > 0.9, same
+    net.set_precision(None)
+
+
+def test_ragged_linear_on_the_fp16_path_leaves_other_rows_untouched(dev):
+    x = W.normal(41, "rl/x", (4 * 128, 256), 1.0).to(dev)
+    w = W.normal(41, "rl/w", (256, 256), 0.06).to(dev)
+    lens = torch.tensor([128, 0, 37, 0], dtype=torch.int32, device=dev)
+    out = torch.full((4 * 128, 256), 7.0, device=dev)
+    ops.linear(x, w, out=out, lens=lens, t_pad=128, precision="f16")
+    assert float((out[128:256] - 7).abs().max()) == 0.0 and float((out[384:] - 7).abs().max()) == 0.0
+    assert float((out[256 + 37:384] - 7).abs().max()) == 0.0
+    want = x.double() @ w.double().t()
+    assert float((out[:128].double() - want[:128]).abs().max()) < 1e-4 and float((out[256:256 + 37].double() - want[256:256 + 37]).abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ glue kernels
+def test_pack_record_kernel(dev):
+    B, k, km = 3, 40, 25
+    kp = torch.floor(W.uniform(51, "pr/k", (B, k, 2), 0.0, 600.0)).to(dev)
+    sc = W.uniform(51, "pr/s", (B, k), 0.0, 1.0).to(dev)
+    lm = torch.randint(-1, 100, (B, k), dtype=torch.int32).to(dev)
+    m0 = torch.randint(-1, 50, (B, km), dtype=torch.int64).to(dev)
+    ms = W.uniform(51, "pr/m", (B, km), 0.0, 1.0).to(dev)
+    rec = ops.pack_record(kp, sc, lm, m0, ms)
+    want = torch.zeros(B, k, 6, device=dev)
+    want[:, :, 0:2], want[:, :, 2], want[:, :, 3] = kp, sc, lm.float()
+    want[:, :, 4] = -1
+    want[:, :km, 4], want[:, :km, 5] = m0.float(), ms
+    assert torch.equal(rec, want)
+    rec = ops.pack_record(kp, sc)
+    assert torch.equal(rec[:, :, :3], want[:, :, :3]) and float(rec[:, :, 3:].abs().max()) == 0.0
+    f = ops._filled((5, 7), dev, torch.int32, -2)
+    assert f.dtype == torch.int32 and bool((f == -2).all()) and float(ops._filled((3, 3), dev).abs().max()) == 0.0
+
+
+def test_secondary_matcher_shape_512_by_1024(dev):
+    """the 512 best keypoints of a query against 1024-keypoint reference sets (unequal, zero-padded token sets);
+    GML indices against the oracle."""
+    from pram_amd.nets.gml import GML
+    net = GML({})
+    net.load_state_dict(H.gml_sd(), strict=True)
+    data, _ = H.pair_data(6, 512, 1024)
+    ref = R.gml_produce_matches(H.gml_sd(), data, p=0.0)
+    r = net.to(dev).eval().produce_matches(_to(data, dev), p=0.0)
+    assert torch.equal(r["matches0"].cpu(), ref["matches0"]) and torch.equal(r["matches1"].cpu(), ref["matches1"])
+    assert H.maxdiff(r["matching_scores0"], ref["matching_scores0"]) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ RCCL, one rank
+def test_gather_records_through_rccl_with_one_rank(dev):
+    """The one collective of the path pushed through RCCL itself (backend 'nccl' on ROCm) with world_size 1 — what a 1-GPU box
+    can execute of the multi-GPU path: communicator set-up on the device, all_gather_into_tensor issued from the main stream
+    after a lane stream produced the record (bench.py's stream pattern), even and padded (shard_sizes) forms."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pram_amd import ops
+from pram_amd.pipeline import gather_records
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+lane = torch.cuda.Stream(device=dev)
+kp = torch.arange(2 * 64 * 2, device=dev, dtype=torch.float32).view(2, 64, 2)
+with torch.cuda.stream(lane):
+    rec = ops.pack_record(kp, kp[:, :, 0].contiguous())
+main = torch.cuda.current_stream(dev)
+main.wait_stream(lane)
+rec.record_stream(main)
+# world size 1 short-circuits in gather_records: drive the collective itself
+full = torch.empty_like(rec)
+dist.all_gather_into_tensor(full, rec.contiguous())
+t = torch.tensor([3.0], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(full, rec) and float(t) == 3.0
+assert torch.equal(gather_records(rec), rec) and torch.equal(gather_records(rec, [2]), rec)
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+''' % str(root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
