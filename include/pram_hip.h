@@ -461,6 +461,23 @@ int pram_proj_dist_top2_f64uv(const float* sim, int ld, const float* kpts, const
 int pram_project_points_f64(const double* xyz, const double* K, const double* Tcw, int n, double im_w, double im_h,
                             double* uvd, int* mask, int* keep_idx, double* uv_keep, int* count, void* stream);
 
+/* ---------------------------------------------------------------- MLP tail as a GEMM pair with the LayerNorm between them
+ * Linear -> LayerNorm -> GELU -> Linear (+ residual): the tail of every attention block (nets/segnetvit.py:87-95,104-106;
+ * nets/gml.py:118-126,151-162), SegNetViT's seg / sc heads (segnetvit.py:157-172) — without a stand-alone LayerNorm + GELU pass
+ * over the hidden layer.  The first GEMM's weights are centred over its outputs on the host (w[j] - mean_j w[j], b[j] - mean b:
+ * LayerNorm is invariant to the shift), so its output is h - mean(h); it also writes the rows' sums of squares, one partial per
+ * 64-column block (row_ssq [parts][m], parts = pram_linear_x3_ssq_parts(m, n, k0 + k1) = ceil(n / 64); the consumer adds them in
+ * ascending order, so the statistics do not depend on the tile configuration a launch picked).  The second GEMM applies
+ * GELU(hidden * rstd * gamma + beta), rstd = 1 / sqrt(sum_p row_ssq[p][row] / k + eps), to its A operand while staging it
+ * (erf by Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7).  Split-fp16 path; lens / t_pad as pram_linear_x3_ragged_f32. */
+int pram_linear_x3_ssq_parts(int m, int n, int k);
+int pram_linear_x3_ssq_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi, const void* w_lo,
+                           float w_scale, const float* bias, float* out, int ldo, float* row_ssq, int m, int n,
+                           const int* lens, int t_pad, void* stream);
+int pram_linear_x3_lngelu_f32(const float* hidden, int ldh, int k, const void* w_hi, const void* w_lo, float w_scale, const float* bias,
+                              const float* residual, int ldr, float* out, int ldo, int m, int n, const float* ln_ssq, int parts,
+                              const float* gamma, const float* beta, float eps, const int* lens, int t_pad, void* stream);
+
 /* Fixed-size per-query result record rec [batch][k][6] fp32 = x, y, score, landmark id, match index, match score — what the
  * single all-gather of the query-sharded job carries (the reference hands the same fields to its pose solver,
  * localization/singlemap3d.py:155-170).  landmark (int32 [batch][k]) and matches0 / mscores0 (int64 / fp32 [batch][km], km <= k:

@@ -30,6 +30,9 @@ _SIGS = {
     "pram_linear_ragged_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P, I, P]),
     "pram_linear_x3_ragged_f32": (I, [P, I, I, P, I, I, P, P, F, P, P, I, P, I, P, P, I, I, I, F, I, P, P, I, P, I, P]),
     "pram_debug_gemm_phases": (I, [P, I]),
+    "pram_linear_x3_ssq_parts": (I, [I, I, I]),
+    "pram_linear_x3_ssq_f32": (I, [P, I, I, P, I, I, P, P, F, P, P, I, P, I, I, P, I, P]),
+    "pram_linear_x3_lngelu_f32": (I, [P, I, I, P, P, F, P, P, I, P, I, I, I, P, I, P, P, F, P, I, P]),
     "pram_linear_x3_qkv_f32": (I, [P, I, I, P, P, F, P, P, P, I, P, P, I, I, I, I, I, I, P, P, I, P, P]),
     "pram_layernorm_gelu_ragged_f32": (I, [P, I, P, I, P, P, I, I, F, P, I, P]),
     "pram_linear_x3p_f32": (I, [P, P, I, I, P, P, I, I, P, P, F, P, P, I, P, I, P, P, I, I, I, F, I, P, P, I, P]),

@@ -79,9 +79,26 @@ __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half
 // ALoad(p, kt) -> raw float4 A[row = tid/8 + 32p][kt*32 + (tid%8)*4 ..+3];  AOk(p, kt) its predicate
 // BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + 64p][kt*32 + (tid%4)*8 ..+7] (fp16); BOk(p, kt) its predicate
 // Adv(kt): wave-uniform loader state, advanced once per chunk (the convolution's tap / channel walk).
+// AXf(v, p, kt): optional transform of a staged A quad (row slot p, chunk kt) before it is split — the LayerNorm + GELU of an MLP's
+// hidden layer applied on the way into the second GEMM (linear.hip); NoXform compiles to nothing.
+struct NoXform {
+    __device__ __forceinline__ void operator()(float4&, int, int) const {}
+};
+
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf);
+
 template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
 __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
                                          float a_scale, f32x16 (&acc)[MI][2], float& amax) {
+    NoXform none;
+    mainloop<MI, WN>(s, adv, la, oka, lb, okb, nk, a_scale, acc, amax, none);
+}
+
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf) {
     using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -104,9 +121,11 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
         float4 a[C::PA];
         uint4 bh[C::PB], bl[C::PB];
         unsigned ok;
+        int kt;
     };
     auto issue = [&](int kt, Regs& g) {
         g.ok = 0u;
+        g.kt = kt;
 #pragma unroll
         for (int p = 0; p < C::PA; ++p) { g.a[p] = la(p, kt); g.ok |= (oka(p, kt) ? 1u : 0u) << p; }
 #pragma unroll
@@ -118,6 +137,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
             const int row = arow + 32 * p;
             float4 v = g.a[p];
             if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            else axf(v, p, g.kt);
             half4 hi, lo;
             split4(v, a_scale, hi, lo, amax);      // amax: range guard (common.h), reported by the caller
             const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;

@@ -84,9 +84,21 @@ __device__ __forceinline__ void dma_tile(_Float16* lds_hi, _Float16* lds_lo, Row
 // DMA: 0 = register staging for both operands; 1 = B (weights) by LDS-DMA (bptr(row, plane, kt) -> row pointer at the chunk's k);
 //      2 = A planes by LDS-DMA as well (aptr likewise; APLANES only).  Rows are clamped by the pointer functors; an out-of-range
 //      row is a duplicate whose outputs the epilogue never stores.
+template <int MI, int WM, int WN, bool APLANES, int ABL, int DMA, class Adv, class ALoad, class AOk, class BLoad, class BOk, class APtr, class BPtr, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, APtr& aptr, BPtr& bptr,
+                                         int nk, float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf);
+
 template <int MI, int WM, int WN, bool APLANES, int ABL, int DMA, class Adv, class ALoad, class AOk, class BLoad, class BOk, class APtr, class BPtr>
 __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, APtr& aptr, BPtr& bptr,
                                          int nk, float a_scale, f32x16 (&acc)[MI][2], float& amax) {
+    gemmx3::NoXform none;
+    mainloop<MI, WM, WN, APLANES, ABL, DMA>(s, adv, la, oka, lb, okb, aptr, bptr, nk, a_scale, acc, amax, none);
+}
+
+// AXf: see gemm_core_x3.h (fp32 A only)
+template <int MI, int WM, int WN, bool APLANES, int ABL, int DMA, class Adv, class ALoad, class AOk, class BLoad, class BOk, class APtr, class BPtr, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, APtr& aptr, BPtr& bptr,
+                                         int nk, float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf) {
     static_assert(DMA < 2 || APLANES, "A can only travel by DMA when it is already split");
     using C = Cfg<MI, WM, WN>;
     const int tid = threadIdx.x;
@@ -109,9 +121,11 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
         uint4 ah[APLANES ? C::QA : 1], al[APLANES ? C::QA : 1];
         uint4 bh[C::QB], bl[C::QB];
         unsigned ok;
+        int kt;
     };
     auto issue = [&](int kt, Regs& g) {
         g.ok = 0u;
+        g.kt = kt;
         if constexpr (DMA < 2 && !(ABL & 16)) {
 #pragma unroll
             for (int p = 0; p < NA; ++p) {
@@ -153,6 +167,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
                 const int row = arow + C::RA * p;
                 float4 v = g.a[p];
                 if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                else axf(v, p, g.kt);
                 half4 hi, lo;
                 split4(v, a_scale, hi, lo, amax);      // amax: range guard (common.h), reported by the caller
                 const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;

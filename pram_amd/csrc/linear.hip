@@ -36,7 +36,56 @@ struct LinArgs {
     void* vt_hi; void* vt_lo; int vt_col0, vt_heads, vt_t, vt_tv;
     // range guard of the split-fp16 path (common.h): the device status word of pram_set_status_word, or nullptr
     unsigned int* status;
+    // LayerNorm statistics across a GEMM pair (the MLP tail: Linear -> LayerNorm -> GELU -> Linear, nets/segnetvit.py:87-95).
+    //   row_ssq (first GEMM, out): [n / 64][m] partial sums of squares of the output rows, one partial per 64-column block; the
+    //     first GEMM's weights are CENTRED over its outputs on the host, so its output IS h - mean(h) and the variance is mean(out^2).
+    //   ln_ssq / ln_parts / ln_gamma / ln_beta / ln_eps (second GEMM, in): its A operand is GELU(a * rstd * gamma + beta), applied
+    //     while the operand is staged; rstd = 1 / sqrt(sum_p ln_ssq[p][row] / K + eps).
+    float* row_ssq;
+    const float* ln_ssq; int ln_parts; const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
+
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, the class of erff's own rounding): one v_rcp, one v_exp and
+// eight multiply-adds instead of erff's ~31 instructions — the GELU of the hidden layer is applied inside a GEMM's staging path,
+// where every VALU instruction competes with the split arithmetic.  tests/test_gpu_round3.py pins it against erff on a dense grid.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);      // exp(-x^2); flushes to 0 for |x| > ~9.3, where erf = 1
+    const float r = fmaf(-poly, e, 1.0f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.0f + erf_as(t * 0.70710678118654752440f)); }
+
+// The A-operand transform of the second GEMM of an MLP tail (gemm_core_x3.h::mainloop, AXf): v = GELU(v * rstd[row] * gamma + beta)
+// on four consecutive k of row slot p.  gamma | beta live in LDS (gb: K floats each); rstd per row slot is computed once per thread.
+template <int PA>
+struct LnGeluXf {
+    const float* gb; int K; int kq;      // kq = this thread's float4 column inside a 32-deep chunk
+    float rstd[PA];
+    __device__ __forceinline__ void operator()(float4& v, int p, int kt) const {
+        const int k = kt * 32 + kq * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gb + k);
+        const float4 b = *reinterpret_cast<const float4*>(gb + K + k);
+        const float rs = rstd[p];
+        v.x = gelu_erf(v.x * rs * g.x + b.x);
+        v.y = gelu_erf(v.y * rs * g.y + b.y);
+        v.z = gelu_erf(v.z * rs * g.z + b.z);
+        v.w = gelu_erf(v.w * rs * g.w + b.w);
+    }
+};
+
+// rstd of row `row` from the first GEMM's partial sums of squares (fixed order: deterministic)
+__device__ __forceinline__ float ln_rstd(const LinArgs& p, int row, int K) {
+    float s = 0.f;
+    for (int q = 0; q < p.ln_parts; ++q) s += p.ln_ssq[(size_t)q * p.m + row];
+    return 1.0f / sqrtf(s / (float)K + p.ln_eps);
+}
 
 __device__ __forceinline__ bool tile_has_rows(const int* __restrict__ lens, int t_pad, int row0, int bm, int m) {
     if (!lens) return true;
@@ -120,6 +169,19 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             if (p.residual) { v0 += q0[e]; v1 += q1[e]; }
             q0[e] = v0;
             q1[e] = v1;
+        }
+        if (p.row_ssq) {
+            // Sum of squares of this wave's 64 columns of every row (lanes 0..31 / 32..63 hold the same rows' other columns),
+            // one partial per 64-column block: every tile configuration has 64-column wave tiles, so a block's partial — and
+            // the consumer's ascending sum over the blocks — is the same bits whichever tile ran (batch == B = 1).
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float sq = (c0ok ? q0[e] * q0[e] : 0.f) + (c1ok ? q1[e] * q1[e] : 0.f);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+                const int row = rbase + acc_row(mi, e, h);
+                if (r == 0 && row < p.m && cbase < p.n) p.row_ssq[(size_t)(cbase >> 6) * p.m + row] = sq;
+            }
         }
         if (p.vt_hi && cbase >= p.vt_col0) {
             // Value head of the projection: straight into the V^T planes.  The accumulator layout IS the key permutation of
@@ -326,13 +388,15 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
 
 // split-fp16 variant (gemm_core_x3.h): wh / wl = the weight matrix * w_scale split into two fp16 planes [n][K] on the
 // host; activations are split while they are staged.  inv = 1 / (ACT_SCALE * w_scale) undoes both scales (exact).
-template <int MI, int WN>
+// LNA: the A operand is the hidden layer of an MLP tail before its LayerNorm + GELU, applied while it is staged (LnGeluXf)
+template <int MI, int WN, bool LNA = false>
 __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, const _Float16* __restrict__ wh,
                                                                    const _Float16* __restrict__ wl, float inv) {
     using namespace gemmx3;
     using C = Cfg<MI, WN>;
     constexpr int BM = C::BM, BN = C::BN;
     __shared__ Smem<MI, WN> smem;
+    __shared__ __attribute__((aligned(16))) float lngb[LNA ? 2 * 1024 : 4];
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -369,7 +433,17 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
     auto adv = [](int) {};
     f32x16 acc[MI][2];
     float amax = 0.f;
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax);
+    if constexpr (LNA) {
+        for (int i = tid; i < K; i += NT) { lngb[i] = p.ln_gamma[i]; lngb[K + i] = p.ln_beta[i]; }
+        LnGeluXf<C::PA> xf;
+        xf.gb = lngb; xf.K = K; xf.kq = akq;
+#pragma unroll
+        for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + 32 * pp, K) : 0.f;
+        __syncthreads();
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax, xf);
+    } else {
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax);
+    }
     x3_range_flag(p.status, amax);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -436,14 +510,16 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3p_kernel(LinArgs p, Pl
 
 // Wide-tile split-fp16 GEMM (gemm_core_x3w.h): 256 x 256 or 128 x 256 outputs per 512-thread workgroup, A as fp32 (split while
 // staged) or as pre-split planes.  Same arithmetic and accumulation order as linear_x3_kernel: bit-identical results.
-template <int MI, int WM, int WN, bool APLANES, int ABL = 0, int DMA = 1>
+template <int MI, int WM, int WN, bool APLANES, int ABL = 0, int DMA = 1, bool LNA = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, PlaneArgs a, const _Float16* __restrict__ wh,
                                                                       const _Float16* __restrict__ wl, float inv) {
     using namespace gemmx3w;
     using C = Cfg<MI, WM, WN>;
     constexpr int BM = C::BM, BN = C::BN;
+    static_assert(!(LNA && APLANES), "the LayerNorm + GELU transform applies to an fp32 A operand");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<MI, WM, WN>& smem = *reinterpret_cast<Smem<MI, WM, WN>*>(smem_raw);
+    float* lngb = reinterpret_cast<float*>(smem_raw + sizeof(Smem<MI, WM, WN>));      // LNA: gamma | beta, 2 K floats behind the stages
     if constexpr (APLANES) {
         if (const int z = blockIdx.y) {  // batched (pram_bgemm_nt_x3p_f32): per-z strides, in halves for the planes, floats for out
             a.a0h += z * p.sa; a.a0l += z * p.sa; wh += z * p.sw; wl += z * p.sw; p.out += z * p.so;
@@ -510,7 +586,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
         auto oka = [&](int pp, int kt) -> bool { return ((rowok >> pp) & 1u) != 0u; };
         auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
         float amax = 0.f;
-        mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);
+        if constexpr (LNA) {
+            for (int i = tid; i < K; i += C::NT) { lngb[i] = p.ln_gamma[i]; lngb[K + i] = p.ln_beta[i]; }
+            LnGeluXf<C::PA> xf;
+            xf.gb = lngb; xf.K = K; xf.kq = akq;
+#pragma unroll
+            for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + C::RA * pp, K) : 0.f;
+            __syncthreads();
+            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax, xf);
+        } else {
+            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);
+        }
         x3_range_flag(p.status, amax);
     }
     unsigned long long te0 = 0ull;
@@ -619,6 +705,12 @@ void launch_linear_x3_t(LinArgs& p, const _Float16* wh, const _Float16* wl, floa
     using C = gemmx3::Cfg<MI, WN>;
     p.tiles_m = cdiv(p.m, C::BM);
     p.tiles_n = cdiv(p.n, C::BN);
+    if constexpr (WN == 2) {      // the LayerNorm + GELU operand transform exists for outputs wider than 64 columns (pram_linear_x3_lngelu_f32 checks)
+        if (p.ln_ssq) {
+            hipLaunchKernelGGL((linear_x3_kernel<MI, WN, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
+            return;
+        }
+    }
     hipLaunchKernelGGL((linear_x3_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
 }
 
@@ -632,6 +724,19 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)linear_x3w_kernel<MI, WM, WN, APLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
+    }
+    if constexpr (!APLANES) {
+        if (p.ln_ssq) {      // A = GELU(LayerNorm(hidden)) applied while staged: gamma | beta ride behind the stages
+            const size_t shm_ln = shm + 2 * (size_t)(p.k0 + p.k1) * sizeof(float);
+            static bool ln_attr_set = false;
+            if (!ln_attr_set) {
+                (void)hipFuncSetAttribute((const void*)linear_x3w_kernel<MI, WM, WN, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(shm + 2 * 1024 * sizeof(float)));
+                ln_attr_set = true;
+            }
+            hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, false, 0, 1, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(C::NT), shm_ln, st, p, a, wh, wl, inv);
+            return;
+        }
     }
     static const char* abl = getenv("PRAM_GEMM_ABLATE");
     const int ab = abl ? atoi(abl) : 0;
@@ -719,8 +824,13 @@ extern "C" int pram_debug_gemm_phases(unsigned long long* out72, int reset) {
 }
 
 struct VtOut { void* hi; void* lo; int col0, heads, t_seq; };
+// LayerNorm coupling of an MLP tail's two GEMMs (LinArgs::row_ssq / ln_*): ssq_out for the first, the rest for the second
+struct LnIo { float* ssq_out; const float* ssq_in; int parts; const float* gamma; const float* beta; float eps; };
 
-static int linear_x3_impl(const VtOut* vt, const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
+// partials per row the first GEMM of an MLP tail writes: one per 64-column block of its output (pram_linear_x3_ssq_parts)
+static int x3_ssq_parts(int n) { return cdiv(n, 64); }
+
+static int linear_x3_impl(const LnIo* ln, const VtOut* vt, const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi,
                                   const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
                                   float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                   int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
@@ -736,6 +846,15 @@ static int linear_x3_impl(const VtOut* vt, const int* lens, int t_pad, const flo
               rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE, lens, t_pad};
     PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_x3_f32: lens needs t_pad > 0");
     p.status = pram_status_ptr();
+    if (ln) {
+        PRAM_REQUIRE(!(ln->ssq_out && (out_hi || vt)), "pram_linear_x3_ssq_f32: row sums go with an fp32 output");
+        p.row_ssq = ln->ssq_out;
+        if (ln->ssq_in) {
+            PRAM_REQUIRE(ln->gamma && ln->beta && ln->parts > 0 && k1 == 0 && k0 % 32 == 0 && k0 <= 1024,
+                         "pram_linear_x3_lngelu_f32: needs gamma / beta / parts, one input segment, K %% 32 == 0, K <= 1024");
+            p.ln_ssq = ln->ssq_in; p.ln_parts = ln->parts; p.ln_gamma = ln->gamma; p.ln_beta = ln->beta; p.ln_eps = ln->eps;
+        }
+    }
     if (vt) {
         PRAM_REQUIRE(vt->hi && vt->lo && out_hi && out_lo, "pram_linear_x3_qkv_f32: null pointer");
         PRAM_REQUIRE(vt->t_seq > 0 && vt->t_seq % 64 == 0 && m % vt->t_seq == 0 && (!lens || t_pad == vt->t_seq),
@@ -763,7 +882,7 @@ extern "C" int pram_linear_x3_f32(const float* a0, int lda0, int k0, const float
                                   const void* w_lo, float w_scale, const float* bias, const float* residual, int ldr,
                                   float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                   int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
-    return linear_x3_impl(nullptr, nullptr, 0, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
+    return linear_x3_impl(nullptr, nullptr, nullptr, 0, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
                           m, n, alpha, flags, rot_cos, rot_sin, rot_cols, stream);
 }
 
@@ -774,8 +893,38 @@ extern "C" int pram_linear_x3_ragged_f32(const float* a0, int lda0, int k0, cons
                                          float* out, int ldo, void* out_hi, void* out_lo, int ldo16, int m, int n, float alpha,
                                          int flags, const float* rot_cos, const float* rot_sin, int rot_cols, const int* lens,
                                          int t_pad, void* stream) {
-    return linear_x3_impl(nullptr, lens, t_pad, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
+    return linear_x3_impl(nullptr, nullptr, lens, t_pad, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, out_hi, out_lo, ldo16,
                           m, n, alpha, flags, rot_cos, rot_sin, rot_cols, stream);
+}
+
+/* MLP tail, first GEMM (nets/segnetvit.py:87-95 mlp.0; nets/gml.py:118-126; the seg head segnetvit.py:157-164): pram_linear_x3_ragged_f32
+   that also writes, per output row, the sum of squares of its outputs — one partial per 64-column block, row_ssq [parts][m] with
+   parts = pram_linear_x3_ssq_parts(m, n, k0 + k1) = ceil(n / 64): summed in ascending order by the consumer, the same bits for
+   every tile configuration.  With the weights CENTRED over the outputs on the host (w - mean_j w[j], b - mean b)
+   the output is h - mean(h) and sum(row_ssq) / n is the LayerNorm's variance: the second GEMM normalises while it stages. */
+extern "C" int pram_linear_x3_ssq_parts(int m, int n, int k) { (void)m; (void)k; return x3_ssq_parts(n); }
+
+extern "C" int pram_linear_x3_ssq_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi, const void* w_lo,
+                                      float w_scale, const float* bias, float* out, int ldo, float* row_ssq, int m, int n,
+                                      const int* lens, int t_pad, void* stream) {
+    PRAM_REQUIRE(row_ssq && out, "pram_linear_x3_ssq_f32: null pointer");
+    LnIo ln{row_ssq, nullptr, 0, nullptr, nullptr, 0.f};
+    return linear_x3_impl(&ln, nullptr, lens, t_pad, a0, lda0, k0, a1, lda1, k1, w_hi, w_lo, w_scale, bias, nullptr, 0, out, ldo, nullptr, nullptr, 0,
+                          m, n, 1.0f, 0, nullptr, nullptr, 0, stream);
+}
+
+/* MLP tail, second GEMM: out = GELU(LayerNorm(hidden)) w^T + bias + residual with the LayerNorm + GELU (nn.LayerNorm + nn.GELU of
+   the reference's nn.Sequential) applied to the A operand while it is staged: hidden [m][k] = the CENTRED output of
+   pram_linear_x3_ssq_f32, ln_ssq [parts][m] its row sums, gamma / beta [k], rstd = 1 / sqrt(sum_p ln_ssq[p][row] / k + eps).
+   erf by Abramowitz & Stegun 7.1.26 (1.5e-7).  k % 32 == 0, k <= 1024. */
+extern "C" int pram_linear_x3_lngelu_f32(const float* hidden, int ldh, int k, const void* w_hi, const void* w_lo, float w_scale, const float* bias,
+                                         const float* residual, int ldr, float* out, int ldo, int m, int n, const float* ln_ssq, int parts,
+                                         const float* gamma, const float* beta, float eps, const int* lens, int t_pad, void* stream) {
+    PRAM_REQUIRE(ln_ssq && out, "pram_linear_x3_lngelu_f32: null pointer");
+    PRAM_REQUIRE(n > 64, "pram_linear_x3_lngelu_f32: n = %d must exceed 64 (narrower outputs: pram_layernorm_gelu_f32 + pram_linear_x3_f32)", n);
+    LnIo ln{nullptr, ln_ssq, parts, gamma, beta, eps};
+    return linear_x3_impl(&ln, nullptr, lens, t_pad, hidden, ldh, k, nullptr, 0, 0, w_hi, w_lo, w_scale, bias, residual, ldr, out, ldo, nullptr, nullptr, 0,
+                          m, n, 1.0f, 0, nullptr, nullptr, 0, stream);
 }
 
 /* The q | k | v projection of an attention block in one call (nets/segnetvit.py:87-95, nets/gml.py:151-159): columns
@@ -787,7 +936,7 @@ extern "C" int pram_linear_x3_qkv_f32(const float* a0, int lda0, int k0, const v
                                       int heads, int t_seq, int m, int n, int flags, const float* rot_cos, const float* rot_sin,
                                       int rot_cols, const int* lens, void* stream) {
     VtOut vt{vt_hi, vt_lo, vt_col0, heads, t_seq};
-    return linear_x3_impl(&vt, lens, lens ? t_seq : 0, a0, lda0, k0, nullptr, 0, 0, w_hi, w_lo, w_scale, bias, nullptr, 0, nullptr, 0, out_hi,
+    return linear_x3_impl(nullptr, &vt, lens, lens ? t_seq : 0, a0, lda0, k0, nullptr, 0, 0, w_hi, w_lo, w_scale, bias, nullptr, 0, nullptr, 0, out_hi,
                           out_lo, ldo16, m, n, 1.0f, flags, rot_cos, rot_sin, rot_cols, stream);
 }
 

@@ -42,7 +42,11 @@ def _fold_proj_into_mlp0(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, 
     bp = sd[prefix + ".proj.bias"].detach().double().cpu()
     hid = wp.shape[0]
     w0a, w0b = w0[:, :w0.shape[1] - hid], w0[:, w0.shape[1] - hid:]
-    return {"mlp0_w": torch.cat([w0a, w0b @ wp], 1).float(), "mlp0_b": (b0 + w0b @ bp).float()}
+    w, b = torch.cat([w0a, w0b @ wp], 1), b0 + w0b @ bp
+    # mlp.0 feeds a LayerNorm, which is invariant to a common shift of its inputs: the weights are centred over the outputs
+    # (fp64), so mlp.0's output is h - mean(h) on every path — and on the split-fp16 path the LayerNorm + GELU ride inside the
+    # second GEMM's staging (ops.mlp_tail) instead of being a pass of their own over the hidden layer
+    return {"mlp0_w": (w - w.mean(0, keepdim=True)).float(), "mlp0_b": (b - b.mean()).float()}
 
 
 def pack_self_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[str, torch.Tensor]:
@@ -79,6 +83,7 @@ def _half_path() -> bool:
 
 
 import os as _os
+FUSED_MLP = _os.environ.get("PRAM_FUSED_MLP", "1") != "0"    # LayerNorm + GELU inside the second GEMM of the MLP tail (0: three kernels)
 FUSED_VT = _os.environ.get("PRAM_FUSED_VT", "1") != "0"      # the projection epilogue writes the V^T planes (0: separate transpose kernel)
 
 
@@ -94,6 +99,9 @@ def _cols(planes, lo: int, hi: int):
 def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor], lens=None, T: int = 0) -> torch.Tensor:
     """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0.  lens / T: ragged sequences — tiles of
     rows beyond every sequence's length are skipped (their rows are never read downstream)."""
+    if ops.gemm_precision == "x3" and FUSED_MLP:
+        return ops.mlp_tail(x, p["mlp0_w"], p["mlp0_b"], p["mlp.1.weight"], p["mlp.1.bias"], p["mlp.3.weight"], p["mlp.3.bias"],
+                            x2=ctx, residual=x, lens=lens, t_pad=T)
     h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx, lens=lens, t_pad=T)
     ops.layernorm_gelu_(h, p["mlp.1.weight"], p["mlp.1.bias"], lens=lens, t_pad=T)
     return ops.linear(h, p["mlp.3.weight"], p["mlp.3.bias"], residual=x, lens=lens, t_pad=T)

@@ -76,13 +76,19 @@ class SegNetViT(blk.PackedCache, nn.Module):
         f = lambda k: sd[k].detach().float().contiguous().to(dev)
         heads = ["seg"] + (["sc"] if self.with_sc else [])
         extra = {f"{h}{i}_{n[0]}": f(f"{h}.{i}.{n}") for h in heads[1:] for i in (0, 1, 3) for n in ("weight", "bias")}
+        # the first Linear of a head feeds a LayerNorm: centred over its outputs at pack time (ops.center_linear), so that the
+        # LayerNorm + GELU can ride inside the second GEMM on the split-fp16 path (ops.mlp_tail)
+        cen = {}
+        for h in heads:
+            w, b = ops.center_linear(sd[f"{h}.0.weight"], sd[f"{h}.0.bias"])
+            cen[f"{h}0_w"], cen[f"{h}0_b"] = w.to(dev), b.to(dev)
         return {
             **extra,
+            **cen,
             "Wr": f("kenc.Wr.weight"),
             "in_w": f("input_proj.weight"), "in_b": f("input_proj.bias"),
             "layers": [blk.pack_self_block(sd, f"gnn.layers.{i}", dev) for i in range(self.n_layers)],
-            "seg0_w": f("seg.0.weight"), "seg0_b": f("seg.0.bias"), "seg1_w": f("seg.1.weight"),
-            "seg1_b": f("seg.1.bias"), "seg3_w": f("seg.3.weight"), "seg3_b": f("seg.3.bias"),
+            "seg1_w": f("seg.1.weight"), "seg1_b": f("seg.1.bias"), "seg3_w": f("seg.3.weight"), "seg3_b": f("seg.3.bias"),
         }
 
     def preprocess(self, data):
@@ -111,13 +117,16 @@ class SegNetViT(blk.PackedCache, nn.Module):
         for lp in P["layers"]:
             x = blk.self_block(x, lp, cos, sin, B, N, lens)
         kw = dict(lens=lens, t_pad=N)      # ragged like the layers: rows beyond a frame's keypoint count are never read or written
-        h = ops.linear(x, P["seg0_w"], P["seg0_b"], **kw)
-        ops.layernorm_gelu_(h, P["seg1_w"], P["seg1_b"], **kw)
         # the logits of rows beyond a frame's keypoint count read zero (they are the tensor the caller sees), not leftovers
         o0 = None if lens is None else ops._filled((B * N, P["seg3_w"].shape[0]), x.device)
-        out = ops.linear(h, P["seg3_w"], P["seg3_b"], out=o0, **kw)
+        if ops.gemm_precision == "x3" and blk.FUSED_MLP and P["seg3_w"].shape[0] > 64:
+            out = ops.mlp_tail(x, P["seg0_w"], P["seg0_b"], P["seg1_w"], P["seg1_b"], P["seg3_w"], P["seg3_b"], out=o0, **kw)
+        else:
+            h = ops.linear(x, P["seg0_w"], P["seg0_b"], **kw)
+            ops.layernorm_gelu_(h, P["seg1_w"], P["seg1_b"], **kw)
+            out = ops.linear(h, P["seg3_w"], P["seg3_b"], out=o0, **kw)
         output = {'prediction': out.view(B, N, -1)}
-        if self.with_sc:
+        if self.with_sc:      # three outputs: narrower than the fused tail takes
             h = ops.linear(x, P["sc0_w"], P["sc0_b"], **kw)
             ops.layernorm_gelu_(h, P["sc1_w"], P["sc1_b"], **kw)
             output['sc'] = ops.linear(h, P["sc3_w"], P["sc3_b"], **kw).view(B, N, 3)

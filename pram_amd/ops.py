@@ -139,6 +139,52 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def mlp_tail(x: torch.Tensor, w0c: torch.Tensor, b0c: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w3: torch.Tensor,
+             b3: Optional[torch.Tensor], *, x2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             eps: float = 1e-5, lens: Optional[torch.Tensor] = None, t_pad: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """residual + Linear(w3, b3)(GELU(LayerNorm(Linear(w0, b0)([x | x2])))) on the split-fp16 path as TWO kernels: the first GEMM
+    (w0c / b0c = the weights centred over their outputs, center_linear()) writes h - mean(h) and the rows' sums of squares, the
+    second normalises and GELUs its operand while it stages it (pram_linear_x3_ssq_f32 / pram_linear_x3_lngelu_f32).  Shapes the
+    fast path cannot take (K % 32 != 0, hidden > 1024) raise."""
+    L = _lib.load()
+    x = x.contiguous()
+    m, k0 = _rows2d(x, "x")
+    k1 = 0
+    if x2 is not None:
+        x2 = x2.contiguous()
+        m2, k1 = _rows2d(x2, "x2")
+        assert m2 == m
+    hid = w0c.shape[0]
+    n = w3.shape[0]
+    if (k0 + k1) % 32 or (k1 and k0 % 32) or hid % 32 or hid > 1024 or w0c.shape[1] != k0 + k1 or w3.shape[1] != hid:
+        raise _lib.PramHipError(f"mlp_tail: unsupported shapes K={k0}+{k1}, hidden={hid}")
+    if lens is not None:
+        assert t_pad > 0 and m % t_pad == 0 and lens.dtype == torch.int32 and lens.numel() == m // t_pad
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    if m == 0:
+        return out
+    parts = int(L.pram_linear_x3_ssq_parts(m, hid, k0 + k1))
+    h = torch.empty(m, hid, device=x.device, dtype=torch.float32)
+    ssq = torch.empty(parts, m, device=x.device, dtype=torch.float32)
+    wh, wl, ws = split_weight(w0c.contiguous())
+    _lib.check(L.pram_linear_x3_ssq_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(wh), _p(wl), ws, _p(b0c), _p(h), hid, _p(ssq), m, hid,
+                                        _p(lens), int(t_pad), _st()), "pram_linear_x3_ssq_f32")
+    if residual is not None:
+        residual = residual.contiguous()
+    wh, wl, ws = split_weight(w3.contiguous())
+    _lib.check(L.pram_linear_x3_lngelu_f32(_p(h), hid, hid, _p(wh), _p(wl), ws, _p(b3), _p(residual), n, _p(out), n, m, n, _p(ssq), parts,
+                                           _p(gamma), _p(beta), float(eps), _p(lens), int(t_pad), _st()), "pram_linear_x3_lngelu_f32")
+    return out
+
+
+def center_linear(w: torch.Tensor, b: torch.Tensor):
+    """(w - mean over the outputs, b - mean) in fp64 -> fp32: a Linear whose output is h - mean(h).  LayerNorm(h) only needs the
+    centred values (it is invariant to the shift), so a Linear that feeds a LayerNorm can be centred once at pack time."""
+    wd, bd = w.detach().double().cpu(), b.detach().double().cpu()
+    return (wd - wd.mean(0, keepdim=True)).float().contiguous(), (bd - bd.mean()).float().contiguous()
+
+
 def linear_qkv_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, t_seq: int,
                       rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, lens: Optional[torch.Tensor] = None):
     """The q | k | v (or qk | v) projection of an attention block on the split-fp16 path, values written transposed:

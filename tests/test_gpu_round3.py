@@ -282,6 +282,69 @@ def test_ragged_linear_on_the_fp16_path_leaves_other_rows_untouched(dev):
     assert float((out[:128].double() - want[:128]).abs().max()) < 1e-4 and float((out[256:256 + 37].double() - want[256:256 + 37]).abs().max()) < 1e-4
 
 
+# ------------------------------------------------------------------------------------------------ MLP tail as a GEMM pair
+@pytest.mark.parametrize("shape", [(16384, 256, 256, 512, 256), (2048, 256, 256, 512, 256), (4096, 256, 0, 1024, 113), (20000, 256, 256, 512, 256),
+                                   (300, 128, 0, 256, 96)])
+def test_mlp_tail_pair_vs_fp64_and_vs_three_kernels(dev, shape):
+    """Linear -> LayerNorm -> GELU -> Linear + residual as two kernels (centred first GEMM + row sums of squares; LayerNorm + GELU
+    applied to the second GEMM's operand while staged, erf by A&S 7.1.26) against an fp64 reference and against the three-kernel
+    path (stand-alone LayerNorm + GELU with exact erff), wide and narrow tiles, ragged rows."""
+    m, k0, k1, hid, n = shape
+    x = W.normal(61, f"mt/x{m}", (m, k0), 1.0).to(dev)
+    x2 = W.normal(61, f"mt/x2{m}", (m, k1), 1.0).to(dev) if k1 else None
+    w0 = W.normal(61, "mt/w0", (hid, k0 + k1), (k0 + k1) ** -0.5).to(dev)
+    b0 = (W.normal(61, "mt/b0", (hid,), 0.3) + 0.7).to(dev)              # a common offset: what the centring removes
+    g = (1.0 + W.normal(61, "mt/g", (hid,), 0.2)).to(dev)
+    bt = W.normal(61, "mt/bt", (hid,), 0.2).to(dev)
+    w3 = W.normal(61, "mt/w3", (n, hid), hid ** -0.5).to(dev)
+    b3 = W.normal(61, "mt/b3", (n,), 0.1).to(dev)
+    res = W.normal(61, f"mt/r{m}", (m, n), 1.0).to(dev)
+    w0c, b0c = [t.to(dev) for t in ops.center_linear(w0, b0)]
+    got = ops.mlp_tail(x, w0c, b0c, g, bt, w3, b3, x2=x2, residual=res)
+    h = ops.linear(x, w0, b0, x2=x2, precision="x3")
+    ops.layernorm_gelu_(h, g, bt)
+    three = ops.linear(h, w3, b3, residual=res, precision="x3")
+    xa = torch.cat([x, x2], 1).double() if k1 else x.double()
+    hh = torch.nn.functional.layer_norm(xa @ w0.double().t() + b0.double(), (hid,), g.double(), bt.double(), 1e-5)
+    want = torch.nn.functional.gelu(hh) @ w3.double().t() + b3.double() + res.double()
+    d_pair, d_three = float((got.double() - want).abs().max()), float((three.double() - want).abs().max())
+    print(f"mlp tail {shape}: pair vs fp64 {d_pair:.2e}, three kernels vs fp64 {d_three:.2e}")
+    assert d_pair < 2e-5 and d_pair < 3 * d_three + 2e-6
+    # ragged: rows beyond their sequence's length are left untouched, the others are the same bits as the full call
+    if m % 4 == 0:
+        t_pad = m // 4
+        lens = torch.tensor([t_pad, 0, t_pad - 37, 5], dtype=torch.int32, device=dev)
+        out = torch.full((m, n), 7.0, device=dev)
+        ops.mlp_tail(x, w0c, b0c, g, bt, w3, b3, x2=x2, residual=res, lens=lens, t_pad=t_pad, out=out)
+        for s_, ln in enumerate(lens.tolist()):
+            a = s_ * t_pad
+            assert torch.equal(out[a:a + ln], got[a:a + ln]) and float((out[a + ln:a + t_pad] - 7).abs().max() if ln < t_pad else 0.0) == 0.0, s_
+
+
+def test_erf_of_the_fused_gelu_against_erff(dev):
+    """The A&S 7.1.26 erf inside the fused GELU, pinned through the kernel: an identity first GEMM feeds a dense grid of hidden
+    values through LayerNorm-free scaling (gamma = std, beta = mean of the grid undo the normalisation), the second GEMM is an
+    identity too — the output is GELU(grid), compared with torch's erf-based GELU in fp64."""
+    hid = 256
+    grid = torch.linspace(-9.0, 9.0, 64 * hid, dtype=torch.float64).view(64, hid)
+    mu, sd = grid.mean(1, keepdim=True), grid.std(1, unbiased=False, keepdim=True)
+    # rows of the grid as inputs of an identity Linear: after centring the first GEMM emits grid - mean; the LayerNorm divides by
+    # sqrt(var + eps); gamma / beta are per column, so each ROW is restored only up to its own (mu, sd): use one row at a time
+    eye = torch.eye(hid, device=dev)
+    zero = torch.zeros(hid, device=dev)
+    worst = 0.0
+    for r in range(0, 64, 7):
+        row = grid[r:r + 1].float().to(dev).repeat(64, 1).contiguous()
+        w0c, b0c = [t.to(dev) for t in ops.center_linear(eye, zero)]
+        g = torch.full((hid,), float(torch.sqrt(sd[r] ** 2 + 1e-5)), device=dev)
+        bt = torch.full((hid,), float(mu[r]), device=dev)
+        got = ops.mlp_tail(row, w0c, b0c, g, bt, eye, None)[0].double().cpu()
+        want = torch.nn.functional.gelu(grid[r])
+        worst = max(worst, float((got - want).abs().max()))
+    print(f"fused GELU (A&S erf) vs fp64 GELU on [-9, 9]: max |d| = {worst:.2e}")
+    assert worst < 3e-6          # split-fp16 identity products + fp32 LayerNorm arithmetic around a 1.5e-7 erf
+
+
 # ------------------------------------------------------------------------------------------------ glue kernels
 def test_pack_record_kernel(dev):
     B, k, km = 3, 40, 25
