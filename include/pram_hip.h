@@ -461,6 +461,25 @@ int pram_proj_dist_top2_f64uv(const float* sim, int ld, const float* kpts, const
 int pram_project_points_f64(const double* xyz, const double* K, const double* Tcw, int n, double im_w, double im_h,
                             double* uvd, int* mask, int* keep_idx, double* uv_keep, int* count, void* stream);
 
+/* Per-layer bookkeeping of the batched AdaGML loop (nets/adagml.py:352-380 per pair; here `pairs` pairs at once, no host read):
+ * commits the pruned token counts (lens_new / n_below of pram_adagml_prune_f32; NULL on layer 0) for the still-active pairs,
+ * evaluates check_if_stop (adagml.py:522-531: 1 - below / (m + n) > 0.95, fp32) — every active pair stops when `last` — and lets the
+ * pairs that stop here commit lens_final / ind_final / stop_layer.  Token sets 0..pairs-1 are the query sets, pairs..2*pairs-1 the
+ * reference sets.  Outputs: lens_out (current counts), lens_stop (counts of the pairs stopping at this layer, 0 elsewhere: the
+ * ragged out_proj GEMM), lens_eff (counts of the pairs still active afterwards, 0 elsewhere: the next layer).  The *_in / *_out
+ * state buffers must differ (ping-pong). */
+int pram_adagml_layer_state(const int* active_in, int* active_out, const int* lens_in, int* lens_out, const int* lens_new,
+                            const int* n_below, const float* num_points, int* tiny, int* stop_layer, int* lens_final,
+                            int* lens_stop, int* lens_eff, const int* ind, int* ind_final, int pairs, int t_max, int layer,
+                            int last, void* stream);
+/* score4[token] = (col_self, col_cross, 0, 0): the two attention scores per token the pooling head reads (adagml.py:132). */
+int pram_adagml_scores4_f32(const float* col_self, const float* col_cross, float* score4, long long tokens, void* stream);
+/* pram_adagml_prune_f32 with the logits at a stride (column 0 of the pooling head's padded [rows][4] output). */
+int pram_adagml_prune_ld_f32(const float* conf_logit, int ld_logit, float thr, int n_min_tokens, const int* lens_in,
+                             const float* x_in, const float* cos_in, const float* sin_in, const int* ind_in,
+                             float* x_out, float* cos_out, float* sin_out, int* ind_out, int* lens_out,
+                             int* n_below, float* conf_out, int* row_map, int sets, int t_max, int ldx, void* stream);
+
 /* ---------------------------------------------------------------- MLP tail as a GEMM pair with the LayerNorm between them
  * Linear -> LayerNorm -> GELU -> Linear (+ residual): the tail of every attention block (nets/segnetvit.py:87-95,104-106;
  * nets/gml.py:118-126,151-162), SegNetViT's seg / sc heads (segnetvit.py:157-172) — without a stand-alone LayerNorm + GELU pass

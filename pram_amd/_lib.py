@@ -62,6 +62,9 @@ _SIGS = {
     "pram_sinkhorn_match_f32": (I, [P, I, P, P, P, I, F, P, I, P, P, P, P, I, I, I, P, P]),
     "pram_dual_softmax_match_f32": (I, [P, I, P, P, P, F, P, I, P, P, P, P, I, I, I, P, P]),
     "pram_adagml_prune_f32": (I, [P, F, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "pram_adagml_layer_state": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "pram_adagml_scores4_f32": (I, [P, P, P, LL, P]),
+    "pram_adagml_prune_ld_f32": (I, [P, I, F, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "pram_adagml_scatter_f32": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "pram_conv2d_nhwc_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),
     "pram_conv2d_nhwc_f16_f32": (I, [P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, P]),

@@ -520,9 +520,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<MI, WM, WN>& smem = *reinterpret_cast<Smem<MI, WM, WN>*>(smem_raw);
     float* lngb = reinterpret_cast<float*>(smem_raw + sizeof(Smem<MI, WM, WN>));      // LNA: gamma | beta, 2 K floats behind the stages
+    // the plane pointers as four separate scalars: selected as `plane ? lo : hi` out of the (by-value) argument struct, the pair
+    // was read through a dynamically indexed private copy of the struct (56 bytes of scratch, round 2's ISA metadata)
+    const _Float16* a0h = a.a0h;
+    const _Float16* a0l = a.a0l;
+    const _Float16* a1h = a.a1h;
+    const _Float16* a1l = a.a1l;
+    const int alda0 = a.lda0, alda1 = a.lda1;
     if constexpr (APLANES) {
         if (const int z = blockIdx.y) {  // batched (pram_bgemm_nt_x3p_f32): per-z strides, in halves for the planes, floats for out
-            a.a0h += z * p.sa; a.a0l += z * p.sa; wh += z * p.sw; wl += z * p.sw; p.out += z * p.so;
+            a0h += z * p.sa; a0l += z * p.sa; wh += z * p.sw; wl += z * p.sw; p.out += z * p.so;
         }
     }
     const int nblk = p.tiles_m * p.tiles_n;
@@ -549,21 +556,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
 #pragma unroll
         for (int pp = 0; pp < C::QA; ++pp) {
             const size_t rc = (size_t)min(row0 + qrow + C::RQ * pp, mlast);
-            aoff0[pp] = rc * a.lda0 + qsl * 8;
-            aoff1[pp] = rc * a.lda1 + qsl * 8;
+            aoff0[pp] = rc * alda0 + qsl * 8;
+            aoff1[pp] = rc * alda1 + qsl * 8;
         }
         auto la = [&](int pp, int kt, int plane) -> uint4 {
             const int k = kt * BK;
             if (k >= p.k0 && p.k1 > 0)                                       // wave-uniform: k0 % 32 == 0
-                return *reinterpret_cast<const uint4*>((plane ? a.a1l : a.a1h) + aoff1[pp] + (k - p.k0));
-            return *reinterpret_cast<const uint4*>((plane ? a.a0l : a.a0h) + aoff0[pp] + k);
+                return *reinterpret_cast<const uint4*>((plane ? a1l : a1h) + aoff1[pp] + (k - p.k0));
+            return *reinterpret_cast<const uint4*>((plane ? a0l : a0h) + aoff0[pp] + k);
         };
         auto oka = [&](int pp, int kt) -> bool { return (row0 + qrow + C::RQ * pp) < p.m; };
         auto aptr = [&](int row, int plane, int kt) -> const _Float16* {
             const size_t rc = (size_t)min(row0 + row, mlast);
             const int k = kt * BK;
-            if (k >= p.k0 && p.k1 > 0) return (plane ? a.a1l : a.a1h) + rc * a.lda1 + (k - p.k0);
-            return (plane ? a.a0l : a.a0h) + rc * a.lda0 + k;
+            if (k >= p.k0 && p.k1 > 0) return (plane ? a1l : a1h) + rc * alda1 + (k - p.k0);
+            return (plane ? a0l : a0h) + rc * alda0 + k;
         };
         float amax = 0.f;      // planes in: nothing is split here
         mainloop<MI, WM, WN, true, ABL, (DMA ? 2 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);

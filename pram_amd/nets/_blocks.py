@@ -157,7 +157,7 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
         if want_colmean:
             ctx, lse = ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, want_lse=True, kv_shift=B)
             col = ops.attention_colmean_x3(qk3, qk3, lse, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
-            return _mlp_tail(x, ctx, p, lens, T), col[:B], col[B:]
+            return _mlp_tail(x, ctx, p, lens, T), col
         return _mlp_tail(x, ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B), p, lens, T)
     if _half_path() and not want_colmean:
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], half_copy="only")
@@ -172,7 +172,7 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
         ctx, lse = ops.attention_cross(qk, v, B, HEADS, T, scale, lens, want_lse=True)
         col = ops.attention_cross_colmean(qk, lse, B, HEADS, T, scale, lens)
         # rows 0..B-1: attn10 column means -> per set-0 token ; rows B..2B-1: attn01 column means -> per set-1 token
-        return _mlp_tail(x, ctx, p, lens, T), col[:B], col[B:]
+        return _mlp_tail(x, ctx, p, lens, T), col
     ctx = ops.attention_cross(qk, v, B, HEADS, T, scale, lens)
     return _mlp_tail(x, ctx, p, lens, T)
 

@@ -116,7 +116,8 @@ class AdaGML(GML):
         return (m_current + n_current) / (m_last + n_last) > confidence
 
     def _pool_logit(self, pp, x, score4, lens=None, T: int = 0):
-        """PoolingLayer.forward up to the pre-sigmoid logit (nets/adagml.py:132-136); rows beyond lens are skipped."""
+        """PoolingLayer.forward up to the pre-sigmoid logit (nets/adagml.py:132-136); rows beyond lens are skipped.  -> [rows, 4]:
+        the last Linear is padded to four outputs (16-byte rows), the logit is column 0."""
         kw = dict(lens=lens, t_pad=T)
         s = ops.linear(score4, pp["se0_w"], pp["se0_b"], **kw)
         ops.layernorm_gelu_(s, pp["se1_w"], pp["se1_b"], **kw)
@@ -124,7 +125,7 @@ class AdaGML(GML):
         xx = ops.linear(x, pp["proj_w"], pp["proj_b"], **kw)
         h = ops.linear(xx, pp["pr0_w"], pp["pr0_b"], x2=s, **kw)
         ops.layernorm_gelu_(h, pp["pr1_w"], pp["pr1_b"], **kw)
-        return ops.linear(h, pp["pr3_w"], pp["pr3_b"], **kw)[:, 0].contiguous()
+        return ops.linear(h, pp["pr3_w"], pp["pr3_b"], **kw)
 
     @torch.no_grad()
     @blk.with_model_precision
@@ -151,61 +152,53 @@ class AdaGML(GML):
         ind = torch.zeros(2 * B, T, device=dev, dtype=torch.int32)
         ind[:B, :m] = torch.arange(m, device=dev, dtype=torch.int32)
         ind[B:, :n] = torch.arange(n, device=dev, dtype=torch.int32)
+        ind = ind.contiguous()
         l0 = data.get('lens0')
         l1 = data.get('lens1')
         lens = torch.cat([l0.int() if l0 is not None else torch.full((B,), m, device=dev, dtype=torch.int32),
                           l1.int() if l1 is not None else torch.full((B,), n, device=dev, dtype=torch.int32)]).contiguous()
-        num_points = (lens[:B] + lens[B:]).float()            # m + n of the ORIGINAL sets (adagml.py:370)
-        active = torch.ones(B, device=dev, dtype=torch.bool)
-        tiny = torch.zeros(B, device=dev, dtype=torch.bool)        # run(): a still-active pair was pruned to <= 5 tokens
-        stop_layer = torch.full((B,), -1, device=dev, dtype=torch.int32)
+        num_points = (lens[:B] + lens[B:]).float().contiguous()            # m + n of the ORIGINAL sets (adagml.py:370)
+        # per-pair state on the device (ops.adagml_layer_state, one kernel per layer): which pairs still run, their token counts,
+        # whether a still-running pair was pruned to <= 5 tokens (run()), the layer a pair stopped at and what it held then
+        active = ops._filled((B,), dev, torch.int32, 1)
+        tiny = ops._filled((B,), dev, torch.int32)
+        stop_layer = ops._filled((B,), dev, torch.int32, -1)
         d = self.config['hidden_dim']
         planes_md = blk._split_path() and d % 32 == 0       # matching descriptors as split planes: the score matrix runs on the fp16 pipe too
-        md_final = None if planes_md else torch.zeros(2 * B, T, d, device=dev, dtype=torch.float32)
-        md_planes = torch.zeros(2, 2 * B * T, d, device=dev, dtype=torch.float16) if planes_md else None
+        md_final = None if planes_md else ops._filled((2 * B, T, d), dev)
+        md_planes = ops._filled((2, 2 * B * T, d // 2), dev).view(torch.float16) if planes_md else None
         lens_final = lens.clone()
         ind_final = ind.clone()
+        lens_eff = lens
         x = ops.linear(X.view(2 * B * T, -1), P["in_w"], P["in_b"])
         nI = self.n_layers
         for ni in range(nI):
-            lens_eff = torch.where(active.repeat(2), lens, torch.zeros_like(lens)).contiguous()
+            last = ni == nI - 1
             x, col_self = blk.self_block(x, P["self"][ni], cos.view(-1, 32), sin.view(-1, 32), 2 * B, T, lens_eff, want_colmean=True)
-            x, col0, col1 = blk.cross_block(x, P["cross"][ni], B, T, lens_eff, want_colmean=True)
-            score4 = torch.zeros(2 * B, T, 4, device=dev, dtype=torch.float32)
-            score4[:, :, 0] = col_self
-            score4[:B, :, 1], score4[B:, :, 1] = col0, col1
-            logit = self._pool_logit(P["pool"][ni], x, score4.view(2 * B * T, 4), lens_eff, T).view(2 * B, T)
-            stop_now = torch.zeros_like(active)
+            x, col_cross = blk.cross_block(x, P["cross"][ni], B, T, lens_eff, want_colmean=True)
+            score4 = ops.adagml_scores4(col_self, col_cross)
+            logit4 = self._pool_logit(P["pool"][ni], x, score4, lens_eff, T)
+            lens_new = n_below = None
             if ni >= 1:
                 thr = self.confidence_threshold(ni)
                 x3, cos, sin, ind, lens_new, n_below, conf = ops.adagml_prune(
-                    logit, thr, self.n_min_tokens, lens_eff, x.view(2 * B, T, -1), cos, sin, ind, want_conf=probes is not None)
+                    logit4, thr, self.n_min_tokens, lens_eff, x.view(2 * B, T, -1), cos, sin, ind, want_conf=probes is not None, ld_logit=4)
                 x = x3.view(2 * B * T, -1)
-                lens = torch.where(active.repeat(2), lens_new, lens)
-                tiny = tiny | (active & ((lens[:B] <= 5) | (lens[B:] <= 5)))
                 if probes is not None:
                     probes[f"conf_{ni}"] = conf
-                # check_if_stop (adagml.py:522-531): 1 - #(conf < thr) / (m + n) > 0.95, same fp32 arithmetic
-                below = (n_below[:B] + n_below[B:]).float()
-                stop_now = active & ((1.0 - below / num_points) > 0.95)
             elif probes is not None:
-                probes[f"conf_{ni}"] = torch.sigmoid(logit)
-            if ni == nI - 1:
-                stop_now = active.clone()                  # loop exhausted: use the last layer (adagml.py:374); also n_layers == 1
-            if ni >= 1 or ni == nI - 1:
+                probes[f"conf_{ni}"] = torch.sigmoid(logit4[:, 0].contiguous().view(2 * B, T))
+            # commit the pruned counts, check_if_stop (adagml.py:522-531) and the per-pair commits of the pairs stopping here
+            active, lens, lens_stop, lens_eff = ops.adagml_layer_state(active, lens, lens_new, n_below, num_points, tiny, stop_layer, lens_final,
+                                                                       ind, ind_final, B, T, ni, last)
+            if ni >= 1 or last:
                 # out_proj only for the pairs that stop at this layer, written straight into their rows of md_final: the ragged
                 # GEMM skips every tile of the other pairs (lens 0) and leaves their rows as they are
-                sel = stop_now.repeat(2)
-                lens_stop = torch.where(sel, lens, torch.zeros_like(lens)).contiguous()
                 if planes_md:
                     ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25, split_out="only", out_planes=(md_planes[0], md_planes[1]),
                                lens=lens_stop, t_pad=T)
                 else:
                     ops.linear(x, P["out_w"][ni], P["out_b"][ni], alpha=1.0 / d ** .25, out=md_final.view(2 * B * T, d), lens=lens_stop, t_pad=T)
-                lens_final = torch.where(sel, lens, lens_final)
-                ind_final = torch.where(sel[:, None], ind, ind_final)
-                stop_layer = torch.where(stop_now, torch.full_like(stop_layer, ni), stop_layer)
-                active = active & ~stop_now
         ldc = (T + 3) // 4 * 4
         if planes_md:
             dist = ops.bgemm_nt_planes((md_planes[0][:B * T], md_planes[1][:B * T]), (md_planes[0][B * T:], md_planes[1][B * T:]), B, T, T, ldc=ldc)

@@ -548,7 +548,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
 def attention_colmean(q: torch.Tensor, k: torch.Tensor, lse2: torch.Tensor, batch: int, heads: int, m_max: int,
                       n_max: int, scale: float, q_lens=None, k_lens=None) -> torch.Tensor:
     L = _lib.load()
-    out = torch.zeros(batch, n_max, device=q.device, dtype=torch.float32)
+    out = _filled((batch, n_max), q.device)
     _lib.check(L.pram_attention_colmean_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(lse2), _p(out), _p(q_lens),
                                             _p(k_lens), batch, heads, m_max, n_max, float(scale), _st()),
                "pram_attention_colmean_f32")
@@ -673,7 +673,7 @@ def attention_colmean_x3(q, k, lse2: torch.Tensor, batch: int, heads: int, m_max
         for t in pair:
             assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
         assert pair[0].stride(0) == pair[1].stride(0)
-    out = torch.zeros(batch, n_max, device=lse2.device, dtype=torch.float32)
+    out = _filled((batch, n_max), lse2.device)
     _lib.check(L.pram_attention_x3_colmean_f32(_p(q[0]), _p(q[1]), q[0].stride(0), _p(k[0]), _p(k[1]), k[0].stride(0), _p(lse2), _p(out),
                                                _p(q_lens), _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift), _st()),
                "pram_attention_x3_colmean_f32")
@@ -719,7 +719,7 @@ def attention_cross_colmean(qk: torch.Tensor, lse2: torch.Tensor, pairs: int, he
                             lens=None) -> torch.Tensor:
     """[2*pairs, t_max]: row kb = per token of sequence kb, mean attention received from the other set's queries."""
     L = _lib.load()
-    out = torch.zeros(2 * pairs, t_max, device=qk.device, dtype=torch.float32)
+    out = _filled((2 * pairs, t_max), qk.device)
     _lib.check(L.pram_attention_cross_colmean_f32(_p(qk), qk.stride(0), _p(lse2), _p(out), _p(lens), pairs, heads, t_max,
                                                   float(scale), _st()), "pram_attention_cross_colmean_f32")
     return out
@@ -771,6 +771,10 @@ def _workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
     return new
 
 
+# plans of one Sinkhorn call: at most this many bytes per group of pairs (0 = one call for the whole batch)
+sinkhorn_group_bytes = int(_os.environ.get("PRAM_SINKHORN_GROUP_MB", "0")) << 20
+
+
 def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, threshold: float,
                    m_lens=None, n_lens=None, want_p: bool = False, dual_softmax: bool = False, n_valid: Optional[int] = None):
     """dist [B, M, ldd] (first n_valid (default ldd) columns valid).  Returns dict with matches0/1 (int64),
@@ -780,49 +784,88 @@ def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, thre
     assert dist.is_contiguous() and dist.dim() == 3
     B, M, ldd = dist.shape
     N = n_valid or ldd
-    ws = _workspace(L.pram_sinkhorn_workspace_bytes(B, M, N), dist.device, "sinkhorn")
     m0 = torch.empty(B, M, device=dist.device, dtype=_INT64)
     m1 = torch.empty(B, N, device=dist.device, dtype=_INT64)
     s0 = torch.empty(B, M, device=dist.device, dtype=torch.float32)
     s1 = torch.empty(B, N, device=dist.device, dtype=torch.float32)
     p = torch.zeros(B, M + 1, N + 1, device=dist.device, dtype=torch.float32) if want_p else None
     bs = bin_score.reshape(1).float()
-    if dual_softmax:
-        rc = L.pram_dual_softmax_match_f32(_p(dist), ldd, _p(m_lens), _p(n_lens), _p(bs), float(threshold), _p(p), N + 1,
-                                           _p(m0), _p(m1), _p(s0), _p(s1), B, M, N, _p(ws), _st())
-    else:
-        rc = L.pram_sinkhorn_match_f32(_p(dist), ldd, _p(m_lens), _p(n_lens), _p(bs), int(iters), float(threshold), _p(p),
-                                       N + 1, _p(m0), _p(m1), _p(s0), _p(s1), B, M, N, _p(ws), _st())
-    _lib.check(rc, "pram_sinkhorn_match_f32")
+    # The 20 iterations stream the whole [m + 1, n + 1] plan of every pair: a group of pairs whose plans fit the 256 MB infinity
+    # cache together iterates out of it (35 us per pair and call instead of 67 from HBM, profiles/r02_sinkhorn_batch.txt), so a
+    # large batch runs group after group — same kernels, every pair its own rows: results do not depend on the grouping.
+    per_pair = (M + 1) * ((N + 4) // 4 * 4) * 4
+    group = B if sinkhorn_group_bytes <= 0 else max(1, min(B, sinkhorn_group_bytes // max(per_pair, 1)))
+    for b0 in range(0, B, group):
+        b1 = min(B, b0 + group)
+        nb = b1 - b0
+        ws = _workspace(L.pram_sinkhorn_workspace_bytes(nb, M, N), dist.device, "sinkhorn")
+        sl = lambda t: None if t is None else _p(t[b0:b1])
+        if dual_softmax:
+            rc = L.pram_dual_softmax_match_f32(_p(dist[b0:b1]), ldd, sl(m_lens), sl(n_lens), _p(bs), float(threshold), sl(p), N + 1,
+                                               _p(m0[b0:b1]), _p(m1[b0:b1]), _p(s0[b0:b1]), _p(s1[b0:b1]), nb, M, N, _p(ws), _st())
+        else:
+            rc = L.pram_sinkhorn_match_f32(_p(dist[b0:b1]), ldd, sl(m_lens), sl(n_lens), _p(bs), int(iters), float(threshold), sl(p),
+                                           N + 1, _p(m0[b0:b1]), _p(m1[b0:b1]), _p(s0[b0:b1]), _p(s1[b0:b1]), nb, M, N, _p(ws), _st())
+        _lib.check(rc, "pram_sinkhorn_match_f32")
     out = {"matches0": m0, "matches1": m1, "matching_scores0": s0, "matching_scores1": s1}
     if want_p:
         out["p"] = p
     return out
 
 
-def adagml_prune(logit, thr, n_min_tokens, lens_in, x, cos, sin, ind, want_conf=False):
-    """-> (x_out, cos_out, sin_out, ind_out, lens_out int32 [S], n_below int32 [S], conf or None)"""
+def adagml_prune(logit, thr, n_min_tokens, lens_in, x, cos, sin, ind, want_conf=False, ld_logit: int = 1):
+    """-> (x_out, cos_out, sin_out, ind_out, lens_out int32 [S], n_below int32 [S], conf or None).  ld_logit > 1: ``logit`` is the
+    [S * T, ld_logit] output of the pooling head's padded last Linear and the logits are its column 0, read in place."""
     L = _lib.load()
-    S, T = logit.shape
+    if ld_logit > 1:
+        S, T = x.shape[0], x.shape[1]
+        assert logit.is_contiguous() and logit.numel() == S * T * ld_logit
+    else:
+        S, T = logit.shape
     ldx = x.shape[-1]
     # rows at and beyond the new length of a set are never written — and never read: every consumer is ragged (lens)
-    x_o, cos_o, sin_o, ind_o = torch.empty_like(x), torch.empty_like(cos), torch.empty_like(sin), torch.zeros_like(ind)
+    x_o, cos_o, sin_o, ind_o = torch.empty_like(x), torch.empty_like(cos), torch.empty_like(sin), _filled(tuple(ind.shape), ind.device, torch.int32)
     lens_o = torch.empty(S, device=x.device, dtype=torch.int32)
     n_below = torch.empty(S, device=x.device, dtype=torch.int32)
-    conf = torch.zeros(S, T, device=x.device, dtype=torch.float32) if want_conf else None
+    conf = _filled((S, T), x.device) if want_conf else None
     row_map = torch.empty(S, T, device=x.device, dtype=torch.int32)
-    _lib.check(L.pram_adagml_prune_f32(_p(logit), float(thr), int(n_min_tokens), _p(lens_in), _p(x), _p(cos), _p(sin), _p(ind),
-                                       _p(x_o), _p(cos_o), _p(sin_o), _p(ind_o), _p(lens_o), _p(n_below), _p(conf), _p(row_map),
-                                       S, T, ldx, _st()),
+    _lib.check(L.pram_adagml_prune_ld_f32(_p(logit), int(ld_logit), float(thr), int(n_min_tokens), _p(lens_in), _p(x), _p(cos), _p(sin), _p(ind),
+                                          _p(x_o), _p(cos_o), _p(sin_o), _p(ind_o), _p(lens_o), _p(n_below), _p(conf), _p(row_map),
+                                          S, T, ldx, _st()),
                "pram_adagml_prune_f32")
     return x_o, cos_o, sin_o, ind_o, lens_o, n_below, conf
+
+
+def adagml_scores4(col_self: torch.Tensor, col_cross: torch.Tensor) -> torch.Tensor:
+    """[S, T] self / cross attention scores per token -> [S * T, 4] rows (self, cross, 0, 0): the pooling head's input."""
+    L = _lib.load()
+    assert col_self.is_contiguous() and col_cross.is_contiguous() and col_self.shape == col_cross.shape
+    out = torch.empty(col_self.numel(), 4, device=col_self.device, dtype=torch.float32)
+    _lib.check(L.pram_adagml_scores4_f32(_p(col_self), _p(col_cross), _p(out), col_self.numel(), _st()), "pram_adagml_scores4_f32")
+    return out
+
+
+def adagml_layer_state(active, lens, lens_new, n_below, num_points, tiny, stop_layer, lens_final, ind, ind_final, pairs: int, t_max: int,
+                       layer: int, last: bool):
+    """One layer of the batched AdaGML bookkeeping (pram_adagml_layer_state) -> (active', lens', lens_stop, lens_eff); tiny,
+    stop_layer, lens_final and ind_final are updated in place."""
+    L = _lib.load()
+    dev = lens.device
+    active_o = torch.empty_like(active)
+    lens_o = torch.empty_like(lens)
+    lens_stop = torch.empty_like(lens)
+    lens_eff = torch.empty_like(lens)
+    _lib.check(L.pram_adagml_layer_state(_p(active), _p(active_o), _p(lens), _p(lens_o), _p(lens_new), _p(n_below), _p(num_points), _p(tiny),
+                                         _p(stop_layer), _p(lens_final), _p(lens_stop), _p(lens_eff), _p(ind), _p(ind_final), int(pairs),
+                                         int(t_max), int(layer), int(bool(last)), _st()), "pram_adagml_layer_state")
+    return active_o, lens_o, lens_stop, lens_eff
 
 
 def adagml_scatter(matches0, mscores0, ind0, ind1, lens0, m_full):
     L = _lib.load()
     B, T = matches0.shape
-    out_m = torch.full((B, m_full), -1, device=matches0.device, dtype=_INT64)
-    out_s = torch.zeros(B, m_full, device=matches0.device, dtype=torch.float32)
+    out_m = _filled((B, m_full, 2), matches0.device, torch.int32, -1).view(_INT64).view(B, m_full)      # int64 -1 = two 0xFFFFFFFF words
+    out_s = _filled((B, m_full), matches0.device)
     _lib.check(L.pram_adagml_scatter_f32(_p(matches0), _p(mscores0), _p(ind0), _p(ind1), _p(lens0), B, T, m_full, _p(out_m),
                                          _p(out_s), _st()), "pram_adagml_scatter_f32")
     return out_m, out_s
