@@ -488,7 +488,7 @@ int pram_adagml_prune_ld_f32(const float* conf_logit, int ld_logit, float thr, i
  * 64-column block (row_ssq [parts][m], parts = pram_linear_x3_ssq_parts(m, n, k0 + k1) = ceil(n / 64); the consumer adds them in
  * ascending order, so the statistics do not depend on the tile configuration a launch picked).  The second GEMM applies
  * GELU(hidden * rstd * gamma + beta), rstd = 1 / sqrt(sum_p row_ssq[p][row] / k + eps), to its A operand while staging it
- * (erf by Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7).  Split-fp16 path; lens / t_pad as pram_linear_x3_ragged_f32. */
+ * (GELU = t Phi(t) through a degree-7 fit of the Gaussian tail, |error| <= 7.5e-8 |t|).  Split-fp16 path; lens / t_pad as pram_linear_x3_ragged_f32. */
 int pram_linear_x3_ssq_parts(int m, int n, int k);
 int pram_linear_x3_ssq_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w_hi, const void* w_lo,
                            float w_scale, const float* bias, float* out, int ldo, float* row_ssq, int m, int n,

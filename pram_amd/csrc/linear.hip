@@ -45,22 +45,24 @@ struct LinArgs {
     const float* ln_ssq; int ln_parts; const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, the class of erff's own rounding): one v_rcp, one v_exp and
-// eight multiply-adds instead of erff's ~31 instructions — the GELU of the hidden layer is applied inside a GEMM's staging path,
-// where every VALU instruction competes with the split arithmetic.  tests/test_gpu_round3.py pins it against erff on a dense grid.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);      // exp(-x^2); flushes to 0 for |x| > ~9.3, where erf = 1
-    const float r = fmaf(-poly, e, 1.0f);
-    return copysignf(r, x);
+// GELU(t) = t Phi(t) with the Gaussian tail written as s(|t|) = 0.5 erfc(|t| / sqrt 2) = 2^-q(|t|), q a degree-7 polynomial
+// fitted on [0, 6] (least squares weighted by |t| s, coefficients rounded to fp32; profiles/tools/gelu_fit.py): Phi = 1 - s for
+// t >= 0, s below.  |t ds| <= 7.5e-8 over the whole line — the class of erff's own rounding times t — for seven multiply-adds,
+// one v_exp and four other instructions, where erff costs ~31: the GELU of the hidden layer is applied inside a GEMM's staging
+// path, where every VALU instruction competes with the split arithmetic.  Beyond |t| = 6 the tail is held at s(6) = 1e-9.
+// tests/test_gpu_round3.py pins it against an fp64 GELU on a dense grid.
+__device__ __forceinline__ float gelu_erf(float t) {
+    const float a = fminf(fabsf(t), 6.0f);
+    float q = fmaf(-3.327738795633195e-06f, a, 1.992317265830934e-06f);
+    q = fmaf(q, a, 0.0006240683724172413f);
+    q = fmaf(q, a, -0.0077792988158762455f);
+    q = fmaf(q, a, 0.053078699856996536f);
+    q = fmaf(q, a, 0.4589627683162689f);
+    q = fmaf(q, a, 1.1511503458023071f);
+    q = fmaf(q, a, 0.9999977350234985f);
+    const float sgm = __builtin_amdgcn_exp2f(-q);
+    return t * (t >= 0.f ? 1.0f - sgm : sgm);
 }
-__device__ __forceinline__ float gelu_erf(float t) { return 0.5f * t * (1.0f + erf_as(t * 0.70710678118654752440f)); }
 
 // The A-operand transform of the second GEMM of an MLP tail (gemm_core_x3.h::mainloop, AXf): v = GELU(v * rstd[row] * gamma + beta)
 // on four consecutive k of row slot p.  gamma | beta live in LDS (gb: K floats each); rstd per row slot is computed once per thread.
@@ -174,14 +176,47 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             // Sum of squares of this wave's 64 columns of every row (lanes 0..31 / 32..63 hold the same rows' other columns),
             // one partial per 64-column block: every tile configuration has 64-column wave tiles, so a block's partial — and
             // the consumer's ascending sum over the blocks — is the same bits whichever tile ran (batch == B = 1).
+            // 16 rows (registers) x 32 lanes (columns): a halving butterfly — at every step a lane hands the half of its rows it is
+            // not responsible for to its partner and adds what it receives — needs 8 + 4 + 2 + 1 + 1 = 16 cross-lane moves where a
+            // plain all-reduce of every register needs 80.
+            float v8[8], v4[4], v2[2], v1;
+            {
+                float sq[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float sq = (c0ok ? q0[e] * q0[e] : 0.f) + (c1ok ? q1[e] * q1[e] : 0.f);
+                for (int e = 0; e < 16; ++e) sq[e] = (c0ok ? q0[e] * q0[e] : 0.f) + (c1ok ? q1[e] * q1[e] : 0.f);
+                const bool up = (lane & 16) != 0;
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-                const int row = rbase + acc_row(mi, e, h);
-                if (r == 0 && row < p.m && cbase < p.n) p.row_ssq[(size_t)(cbase >> 6) * p.m + row] = sq;
+                for (int i = 0; i < 8; ++i) {
+                    const float keep = up ? sq[i + 8] : sq[i], send = up ? sq[i] : sq[i + 8];
+                    v8[i] = keep + __shfl_xor(send, 16, 64);
+                }
             }
+            {
+                const bool up = (lane & 8) != 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float keep = up ? v8[i + 4] : v8[i], send = up ? v8[i] : v8[i + 4];
+                    v4[i] = keep + __shfl_xor(send, 8, 64);
+                }
+            }
+            {
+                const bool up = (lane & 4) != 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float keep = up ? v4[i + 2] : v4[i], send = up ? v4[i] : v4[i + 2];
+                    v2[i] = keep + __shfl_xor(send, 4, 64);
+                }
+            }
+            {
+                const bool up = (lane & 2) != 0;
+                const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
+                v1 = keep + __shfl_xor(send, 2, 64);
+            }
+            v1 += __shfl_xor(v1, 1, 64);
+            // lane bits 4..1 = register bits 3..0 of the row this lane ended up with
+            const int e_own = (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1);
+            const int row = rbase + acc_row(mi, e_own, h);
+            if ((lane & 1) == 0 && row < p.m && cbase < p.n) p.row_ssq[(size_t)(cbase >> 6) * p.m + row] = v1;
         }
         if (p.vt_hi && cbase >= p.vt_col0) {
             // Value head of the projection: straight into the V^T planes.  The accumulator layout IS the key permutation of
@@ -923,7 +958,7 @@ extern "C" int pram_linear_x3_ssq_f32(const float* a0, int lda0, int k0, const f
 /* MLP tail, second GEMM: out = GELU(LayerNorm(hidden)) w^T + bias + residual with the LayerNorm + GELU (nn.LayerNorm + nn.GELU of
    the reference's nn.Sequential) applied to the A operand while it is staged: hidden [m][k] = the CENTRED output of
    pram_linear_x3_ssq_f32, ln_ssq [parts][m] its row sums, gamma / beta [k], rstd = 1 / sqrt(sum_p ln_ssq[p][row] / k + eps).
-   erf by Abramowitz & Stegun 7.1.26 (1.5e-7).  k % 32 == 0, k <= 1024. */
+   GELU through a degree-7 fit of the Gaussian tail (gelu_erf: 7.5e-8).  k % 32 == 0, k <= 1024. */
 extern "C" int pram_linear_x3_lngelu_f32(const float* hidden, int ldh, int k, const void* w_hi, const void* w_lo, float w_scale, const float* bias,
                                          const float* residual, int ldr, float* out, int ldo, int m, int n, const float* ln_ssq, int parts,
                                          const float* gamma, const float* beta, float eps, const int* lens, int t_pad, void* stream) {

@@ -287,7 +287,7 @@ def test_ragged_linear_on_the_fp16_path_leaves_other_rows_untouched(dev):
                                    (300, 128, 0, 256, 96)])
 def test_mlp_tail_pair_vs_fp64_and_vs_three_kernels(dev, shape):
     """Linear -> LayerNorm -> GELU -> Linear + residual as two kernels (centred first GEMM + row sums of squares; LayerNorm + GELU
-    applied to the second GEMM's operand while staged, erf by A&S 7.1.26) against an fp64 reference and against the three-kernel
+    applied to the second GEMM's operand while staged, GELU through a fitted Gaussian tail) against an fp64 reference and against the three-kernel
     path (stand-alone LayerNorm + GELU with exact erff), wide and narrow tiles, ragged rows."""
     m, k0, k1, hid, n = shape
     x = W.normal(61, f"mt/x{m}", (m, k0), 1.0).to(dev)
@@ -322,7 +322,7 @@ def test_mlp_tail_pair_vs_fp64_and_vs_three_kernels(dev, shape):
 
 
 def test_erf_of_the_fused_gelu_against_erff(dev):
-    """The A&S 7.1.26 erf inside the fused GELU, pinned through the kernel: an identity first GEMM feeds a dense grid of hidden
+    """The fitted Gaussian tail inside the fused GELU (7.5e-8 |t|), pinned through the kernel: an identity first GEMM feeds a dense grid of hidden
     values through LayerNorm-free scaling (gamma = std, beta = mean of the grid undo the normalisation), the second GEMM is an
     identity too — the output is GELU(grid), compared with torch's erf-based GELU in fp64."""
     hid = 256
@@ -341,7 +341,7 @@ def test_erf_of_the_fused_gelu_against_erff(dev):
         got = ops.mlp_tail(row, w0c, b0c, g, bt, eye, None)[0].double().cpu()
         want = torch.nn.functional.gelu(grid[r])
         worst = max(worst, float((got - want).abs().max()))
-    print(f"fused GELU (A&S erf) vs fp64 GELU on [-9, 9]: max |d| = {worst:.2e}")
+    print(f"fused GELU (fitted tail) vs fp64 GELU on [-9, 9]: max |d| = {worst:.2e}")
     assert worst < 3e-6          # split-fp16 identity products + fp32 LayerNorm arithmetic around a 1.5e-7 erf
 
 
