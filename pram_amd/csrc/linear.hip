@@ -803,9 +803,12 @@ bool launch_linear_x3_wide(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _
     static const char* force = getenv("PRAM_X3_TILE");
     if (force && force[0] == 'n') return false;
     if (p.n < 256 || (p.k0 + p.k1) % 32 != 0) return false;
-    const long big = (long)cdiv(p.m, 256) * cdiv(p.n, 256) * batch;
-    if (!force && (long)cdiv(p.m, 128) * cdiv(p.n, 256) * batch < 192) return false;      // too few wide tiles for 256 CUs: narrow tiles fill the chip better
-    const bool use256 = force ? (force[1] == '2') : big >= 224;
+    const long big = (long)cdiv(p.m, 256) * cdiv(p.n, 256) * batch, small = (long)cdiv(p.m, 128) * cdiv(p.n, 256) * batch;
+    if (!force && small < 192) return false;      // too few wide tiles for 256 CUs: narrow tiles fill the chip better
+    // One workgroup per CU: a launch takes ceil(tiles / 256) rounds.  A 128-row tile costs ~0.55 of a 256-row one (measured), so
+    // the 256-row tiles lose when their last round is mostly empty — 32 768 x 768 (SegNetViT's q | k | v projection) is 384 tiles =
+    // 2 rounds against 768 half tiles = 3 x 0.55 rounds.
+    const bool use256 = force ? (force[1] == '2') : (big >= 224 && 100 * cdiv((int)big, 256) <= 55 * cdiv((int)small, 256));
     if (use256) launch_linear_x3w_t<4, 2, 4, APLANES>(p, a, wh, wl, inv, st, batch);
     else launch_linear_x3w_t<2, 2, 4, APLANES>(p, a, wh, wl, inv, st, batch);
     return true;
