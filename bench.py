@@ -340,7 +340,7 @@ def attention_roofline(probe, precision, dev, step_ms):
     pipe_peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
     peak = pipe_peak / mult
     kern = {"f32": "attention_kernel (v_mfma_f32_32x32x2_f32 flash attention, exact fp32 products)",
-            "x3": "attention_x3_pipe_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per score product, 2 per P.V product from 1024 keys on)",
+            "x3": "attention_x3_pipe_kernel (split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product; mfma_per_product says what this run issued)",
             "f16": "attention_x3_pipe_kernel<HI> (C5 fp16 MFMA path: one product)"}[precision]
     return {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
@@ -457,15 +457,18 @@ class Job:
 
 
 def pin_rank_thread(local: int, world: int):
-    """One host core per rank (the launching thread), spread over the cores this job may use: eight ranks otherwise migrate over
-    a cgroup-limited core set and a descheduled rank stalls the step's barrier.  -> the core, or None."""
+    """Give every rank its own slice of the cores this job may use (the launching thread and every helper thread it starts
+    later — HIP's, RCCL's proxy — inherit it): eight ranks otherwise migrate over one shared core set and a descheduled rank
+    stalls the step's barrier.  A slice, not a single core: the helper threads must not queue behind the launching thread.
+    -> the first core of the slice, or None when there are fewer cores than ranks (left alone)."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        if len(allowed) < world:
+        per = len(allowed) // world
+        if per < 1:
             return None
-        core = allowed[(local * len(allowed)) // world]
-        os.sched_setaffinity(0, {core})
-        return core
+        mine = allowed[local * per:(local + 1) * per]
+        os.sched_setaffinity(0, set(mine))
+        return mine[0]
     except Exception:
         return None
 
@@ -638,11 +641,16 @@ def main():
     if rank == 0 and world == 1 and want_alt:
         alt = {}
 
-        def alt_run(name, note, steps_=3, warm_=2, **kw):
+        def alt_run(name, note, steps_=3, warm_=2, p_split=None, **kw):
             cfg = dict(matcher_name=args.matcher, kpts=args.kpts, n_class=args.n_class, stages=args.stages, inflight=inflight,
                        use_graph=False, precision=None, ref_kpts=0, match_kpts=0)
             cfg.update(kw)
             Bq = cfg.pop("B", B)
+            from pram_amd import _lib
+            L = _lib.load()
+            saved_p = L.pram_attention_x3_set_p_split(-1)
+            if p_split is not None:
+                L.pram_attention_x3_set_p_split(int(p_split))
             try:
                 j = Job(dev, 0, 1, 0, Bq, **cfg)
                 t, _ = j.timed(steps_, warm_, sync_all)
@@ -653,8 +661,12 @@ def main():
                 del j
             except Exception as e:      # an alternative that fails must not take the headline line with it — but it is reported
                 alt[name] = {"error": f"{type(e).__name__}: {e}"[:300], "what": note}
+            finally:
+                L.pram_attention_x3_set_p_split(saved_p)
             torch.cuda.empty_cache()
 
+        alt_run("attention_p_one_fp16", "same step with the soft-max probabilities entering P.V as ONE fp16 (pram_attention_x3_set_p_split(0): two MFMAs per "
+                "product instead of three; logits 7e-4 instead of 4e-5 from the fp32 oracle on flat synthetic attention — not the default)", p_split=0)
         alt_run("adagml", "same step with the AdaGML matcher (BASELINE configs[2] names it; pruning / early exit are data-dependent)", matcher_name="adagml")
         alt_run("exact_f32", "same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)", precision="f32")
         alt_run("gml_512x1024", "secondary matcher shape of SURVEY 8(d): the 512 best keypoints of a query against 1024-keypoint reference sets",

@@ -220,11 +220,11 @@ int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, c
  * probabilities enter as one fp16), three below (pram_attention_x3_mfma_per_tile).  Output fp32.
  * kv_shift as in pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs).
  * Key chunks: from 1024 keys on the keys are reduced in chunks (pram_attention_x3_set_chunk_keys: default 2048 keys), each chunk
- * normalised, parked in `workspace` (pram_attention_x3_workspace_bytes; 0 when a sequence is a single chunk) and folded in chunk
- * order.  One workgroup normally walks all chunks of its 128 query rows; an under-filled launch (pram_attention_x3_is_split: one or
- * two query frames, the reference's online loop localization/loc_by_rec_online.py:109-133) runs groups of chunks as a second grid
- * dimension and folds them in a second kernel: the SAME fold in the SAME order, so the output is bit-identical whichever mode
- * ran.  workspace == NULL (or too small) with more than one chunk: fused with the running fold in registers — same bits, slower. */
+ * normalised and all chunks folded in chunk order.  One workgroup normally walks all chunks of its 128 query rows and folds them
+ * in registers; an under-filled launch (pram_attention_x3_is_split: one or two query frames, the reference's online loop
+ * localization/loc_by_rec_online.py:109-133) runs groups of chunks as a second grid dimension, parks them in `workspace`
+ * (pram_attention_x3_workspace_bytes; 0 when a sequence is a single chunk) and folds them in a second kernel: the SAME fold in
+ * the SAME order, so the output is bit-identical whichever mode ran.  workspace == NULL (or too small): always fused. */
 size_t pram_attention_x3_workspace_bytes(int batch, int heads, int m_max, int n_max);
 int pram_attention_x3_is_split(int batch, int heads, int m_max, int n_max);
 /* tuning / test knob: under-filled launches are split along the keys into as many groups of 512-key chunks as bring the grid to
@@ -233,10 +233,14 @@ int pram_attention_x3_is_split(int batch, int heads, int m_max, int n_max);
 int pram_attention_x3_set_split_target(int workgroups);
 /* keys per chunk (a multiple of 128; default 2048 or the environment's PRAM_ATTN_CHUNK_KEYS), process-wide: set it before the first
  * launch — it fixes where EVERY launch folds its partial soft-maxes (results move in their last bits, consistently for all batch
- * sizes).  Smaller chunks let shorter key sets use the split mode; a fused walk pays for every chunk it parks (+3..8 % kernel time
- * at 1024 keys per chunk, +13 % at 512, for 2048-key sets).  0 = query; returns the value in force. */
+ * sizes).  Smaller chunks let shorter key sets use the split mode; a fused walk pays a spill round trip at every chunk end
+ * (+15 % kernel time at 512 keys per chunk for 2048-key sets, ~1 % at 2048 for 4096-key sets).  0 = query; returns the value. */
 int pram_attention_x3_set_chunk_keys(int keys);
 int pram_attention_x3_mfma_per_tile(int n_max);
+/* probabilities in P V from 1024 keys on: 1 = two fp16 parts (three MFMAs per product; default), 0 = one fp16 (two MFMAs, ~15 % less
+ * attention time, 2^-12 relative rounding per probability: logits 7e-4 instead of 4e-5 from the fp32 oracle on flat attention);
+ * also PRAM_ATTN_P=split|fp16 in the environment.  Negative = query; returns the value in force. */
+int pram_attention_x3_set_p_split(int split);
 int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,
                           const void* vt_hi, const void* vt_lo, float* out, int ldo, float* lse2,
                           const int* q_lens, const int* k_lens, int batch, int heads, int m_max, int n_max,
@@ -496,6 +500,24 @@ int pram_linear_x3_ssq_f32(const float* a0, int lda0, int k0, const float* a1, i
 int pram_linear_x3_lngelu_f32(const float* hidden, int ldh, int k, const void* w_hi, const void* w_lo, float w_scale, const float* bias,
                               const float* residual, int ldr, float* out, int ldo, int m, int n, const float* ln_ssq, int parts,
                               const float* gamma, const float* beta, float eps, const int* lens, int t_pad, void* stream);
+
+/* ---------------------------------------------------------------- fp16 MFMA path (BASELINE C5) with fp16 intermediates in HBM
+ * The single-product path rounds every GEMM / attention operand to fp16 while it stages it; here the producers write those
+ * operands as fp16 (2 bytes per element of HBM traffic): q | k as fp16 rows and v straight into the transposed key-permuted layout
+ * (pram_linear_f16_qkv_h16), the attention context (pram_attention_h16t_h16), the MLP's hidden layer (pram_linear_f16_ssq_h16: host-
+ * centred weights, rows' sums of squares from the fp32 values), normalised and GELU-ed while the second GEMM stages it
+ * (pram_linear_f16_lngelu_f32).  The residual stream stays fp32.  This path's own tolerance. */
+int pram_linear_f16_qkv_h16(const float* a0, int lda0, int k0, const void* w16, const float* bias, void* out16, int ldo16, void* vt16,
+                            int vt_col0, int heads, int t_seq, int m, int n, int flags, const float* rot_cos, const float* rot_sin,
+                            int rot_cols, const int* lens, void* stream);
+int pram_attention_h16t_h16(const void* q16, int ldq, const void* k16, int ldk, const void* vt16, void* out16, int ldo16,
+                            float* lse2, const int* q_lens, const int* k_lens, int batch, int heads, int m_max,
+                            int n_max, float scale, int kv_shift, void* stream);
+int pram_linear_f16_ssq_h16(const float* a0, int lda0, int k0, const void* a1_16, int lda1, int k1, const void* w16, const float* bias,
+                            void* out16, int ldo16, float* row_ssq, int m, int n, void* stream);
+int pram_linear_f16_lngelu_f32(const void* hidden16, int ldh, int k, const void* w16, const float* bias, const float* residual, int ldr,
+                               float* out, int ldo, int m, int n, const float* ln_ssq, int parts, const float* gamma,
+                               const float* beta, float eps, void* stream);
 
 /* Fixed-size per-query result record rec [batch][k][6] fp32 = x, y, score, landmark id, match index, match score — what the
  * single all-gather of the query-sharded job carries (the reference hands the same fields to its pose solver,

@@ -42,6 +42,7 @@ _SIGS = {
     "pram_attention_x3_is_split": (I, [I, I, I, I]),
     "pram_attention_x3_set_split_target": (I, [I]),
     "pram_attention_x3_set_chunk_keys": (I, [I]),
+    "pram_attention_x3_set_p_split": (I, [I]),
     "pram_attention_x3_colmean_f32": (I, [P, P, I, P, P, I, P, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_h16t_f32": (I, [P, I, P, I, P, P, I, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_x3_vt": (I, [P, P, I, P, P, P, I, I, I, P]),
@@ -86,6 +87,10 @@ _SIGS = {
     "pram_proj_dist_top2_f64uv": (I, [P, I, P, P, I, I, I, C.c_double, P, P, P, P]),
     "pram_project_points_f64": (I, [P, P, P, I, C.c_double, C.c_double, P, P, P, P, P, P]),
     "pram_seg_vote": (I, [P, P, I, I, I, P, P, P, P, P, P, P]),
+    "pram_linear_f16_qkv_h16": (I, [P, I, I, P, P, P, I, P, I, I, I, I, I, I, P, P, I, P, P]),
+    "pram_attention_h16t_h16": (I, [P, I, P, I, P, P, I, P, P, P, I, I, I, I, F, I, P]),
+    "pram_linear_f16_ssq_h16": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, P]),
+    "pram_linear_f16_lngelu_f32": (I, [P, I, I, P, P, P, I, P, I, I, I, P, I, P, P, F, P]),
     "pram_pack_record_f32": (I, [P, P, P, P, P, I, I, I, P, P]),
     "pram_fill_u32": (I, [P, C.c_uint, SZ, P]),
     "pram_score_lookup_f32": (I, [P, LL, I, I, P, P, I, I, P, P]),

@@ -44,6 +44,7 @@ struct ArgsX {
     int chunk_tiles;                 // 64-key tiles per key chunk (g_chunk_tiles: even, the same for every launch of the process)
     float* part_o;                   // [nsplit][batch * m_max][heads * D]   normalised chunk outputs
     float* part_l;                   // [nsplit][batch][heads][m_max]        their log2-sum-exp
+    _Float16* out16; int ldo16;      // single-product mode: the context as fp16 [batch * m_max][ldo16] instead of `out` (the next GEMM's operand)
 };
 
 // Key chunks (as attention.hip).  From 1024 keys on, the keys of a sequence are processed in chunks of chunk_tiles tiles: every
@@ -53,12 +54,12 @@ struct ArgsX {
 // (localization/loc_by_rec_online.py:109-133) — makes groups of chunks a grid dimension instead ("split"): each workgroup parks
 // its normalised chunk results in a caller-owned workspace and combine_x3_kernel applies the SAME fold in the SAME order, so the
 // output does not depend on which mode ran, bit for bit: a padded batch element still equals its B = 1 run exactly.
-// Chunk size.  A fused walk parks every chunk but its last (fp32, 8 KB per wave and chunk: the running fold does not fit in the
-// 256 registers of a wave beside the pipeline's two score tiles) and reads them back once at the end.  At the power cap bytes are
-// time: 512-key chunks cost +13 % kernel time at 2048 keys, 1024-key chunks +3...8 % (profiles/r03_x3_attention_chunks.txt).  The
-// default is therefore 2048 keys — the shipped 2048-keypoint configurations run one chunk and pay nothing, 4096 keys run two — and
-// pram_attention_x3_set_chunk_keys lowers it for deployments that want the split mode at 2048 keys (it moves the chunk
-// boundaries of EVERY launch, so results change in their last bits consistently, never between batch sizes).
+// Chunk size.  A fused walk folds a running total at every chunk end; the total does not fit in the 256 registers of a wave
+// beside the pipeline's two score tiles, so each chunk end costs a spill round trip: 512-key chunks +15 % kernel time at 2048
+// keys, 2048-key chunks ~1 % at 4096 keys (profiles/r03_x3_attention_chunks.txt).  The default is therefore 2048 keys — the
+// shipped 2048-keypoint configurations run one chunk and pay nothing, 4096 keys run two — and pram_attention_x3_set_chunk_keys
+// lowers it for deployments that want the split mode at 2048 keys (it moves the chunk boundaries of EVERY launch, so results
+// change in their last bits consistently, never between batch sizes).
 constexpr int DEFAULT_CHUNK_TILES = 32;         // 2048 keys (g_chunk_tiles; pram_attention_x3_set_chunk_keys)
 constexpr int SPLIT_TARGET = 256;               // split launches aim at this many workgroups: one per CU (g_split_target)
 
@@ -361,7 +362,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     const bool q_ok = qrow < qlen;
     if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip); the split mode's first chunk reports it
         if (MODE == 2 && blockIdx.y != 0) return;
-        if (q_ok) {
+        if (q_ok && HI && p.out16) {
+            _Float16* o16 = p.out16 + ((size_t)b * p.m_max + qrow) * p.ldo16 + head * D;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) o16[c * 2 + h] = (_Float16)0.f;
+        } else if (q_ok) {
             float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
 #pragma unroll
             for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -462,15 +467,18 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
     half8 ph[2][2], pl[2][2];
-    // Chunk bookkeeping.  MODE 1 (fused): the normalised result of every finished chunk but the last is PARKED in the workspace —
-    // the same [chunk][row][head * 64 + d] / [chunk][batch][head][row] layout the split mode writes — and folded after the last
-    // tile, by the left fold combine_x3_kernel applies: a running total in registers does not fit beside the two score tiles of
-    // the software pipeline (256 registers at two waves per SIMD; kept there by the compiler it is spilled and reloaded with the
-    // latency exposed at every chunk end: +15 % kernel time = MODE 3, the fallback without a workspace), parked it costs stores
-    // only and one exposed round trip per workgroup.  MODE 0 / 2: one chunk per workgroup.
+    // Chunk bookkeeping.  MODE 1 (fused): a running total (o_tot, l_tot2) is folded at every chunk end by the left fold
+    // combine_x3_kernel applies; it does not fit beside the two score tiles of the software pipeline (256 registers at two waves
+    // per SIMD), the compiler spills and reloads it around the chunk end: ~1 % at 2048-key chunks, 15 % at 512.  MODE 2 (split):
+    // every chunk of the workgroup's key group is PARKED in the workspace, [chunk][row][head * 64 + d] / [chunk][batch][head][row].
+    // MODE 0: one chunk, nothing to fold.
+    // (A fused variant that parked its chunks like MODE 2 and folded them after the last tile — no spill — was dropped: compiled
+    // with two-part probabilities it returned, on ~1 wave in 2500, one output register with the earlier chunks' share missing in
+    // lanes 48..63; inputs in memory were right, draining every counter before the fold did not help, the cause was not found.
+    // tests/test_gpu_round3.py::test_x3_attention_many_workgroups_every_mode repeats the launch that showed it.)
     float l_tot2 = -INFINITY;
-    float o_tot[2][MODE == 3 ? 16 : 1];
-    if constexpr (MODE == 3) {
+    float o_tot[2][MODE == 1 ? 16 : 1];
+    if constexpr (MODE == 1) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o_tot[0][e] = 0.f; o_tot[1][e] = 0.f; }
     }
@@ -488,12 +496,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         const size_t li = ((size_t)b * p.heads + head) * p.m_max + min(qt * BQ + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
         return p.part_l + (size_t)c * p.batch * p.heads * p.m_max + li;
     };
-    // end of a key chunk inside the walk (MODE 1 / 3): normalise it, park it (1) or fold it (3), start afresh
+    // end of a key chunk inside the walk (MODE 1 / 2): normalise it, fold it (1) or park it (2), start afresh
     auto chunk_end = [&](int c) {
         const float l_c = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;      // undoes the 2^14 of P (carried by l_c) and the scale of V
         const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
-        if constexpr (MODE == 1 || MODE == 2) {
+        if constexpr (MODE == 2) {
             if (q_ok) {
                 float* op = part_ptr(c);
 #pragma unroll
@@ -519,19 +527,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         m_run = -1.0e30f;
         l_run = 0.f;
     };
-    // after the last tile: the last chunk normalised in place (oacc), l_tot2 = its log2-sum-exp; MODE 1 / 3 then fold everything
-    // MODE 1: chunk 0 of the parked results is requested before the last tile's P V step (pre / lpre: the registers of the score
-    // tile the soft-max has just consumed) so that its round trip is not exposed at the end of the workgroup
-    float4 pre[2][4];
-    float lpre = 0.f;
-    auto fetch_part = [&](int c, float4 (&v)[2][4], float& l) {
-        const float* op = part_ptr(c);
-#pragma unroll
-        for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v[dn][g] = *reinterpret_cast<const float4*>(op + dn * 32 + 8 * g + 4 * h);
-        l = *part_lse(c);
-    };
+    // after the last tile: the last chunk normalised in place (oacc), l_tot2 = its log2-sum-exp; MODE 1 then folds it into the total
     auto finish = [&]() {
         const float l_c = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;
@@ -539,47 +535,6 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { oacc[0][e] *= inv; oacc[1][e] *= inv; }
         if constexpr (MODE == 1) {
-            // the left fold of combine_x3_kernel over the parked chunks 0 .. nc - 2 and the last one (in registers); the next
-            // chunk's values are requested before the current one is folded
-            const int nc = (nkt - 1) / CT + 1;
-            float ot[2][16], lt = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { ot[0][e] = 0.f; ot[1][e] = 0.f; }
-            float4 cur[2][4], nxt[2][4];
-            float lcur = lpre, lnxt = 0.f;
-#pragma unroll
-            for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) cur[dn][g] = pre[dn][g];
-            for (int c = 0; c + 1 < nc; ++c) {
-                if (c + 2 < nc) fetch_part(c + 1, nxt, lnxt);
-                float at, ac, lnew;
-                fold_weights(lt, lcur, &at, &ac, &lnew);
-#pragma unroll
-                for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        ot[dn][4 * g + 0] = fold_value(ot[dn][4 * g + 0], cur[dn][g].x, at, ac);
-                        ot[dn][4 * g + 1] = fold_value(ot[dn][4 * g + 1], cur[dn][g].y, at, ac);
-                        ot[dn][4 * g + 2] = fold_value(ot[dn][4 * g + 2], cur[dn][g].z, at, ac);
-                        ot[dn][4 * g + 3] = fold_value(ot[dn][4 * g + 3], cur[dn][g].w, at, ac);
-                    }
-                lt = lnew;
-#pragma unroll
-                for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) cur[dn][g] = nxt[dn][g];
-                lcur = lnxt;
-            }
-            float at, ac, lnew;
-            fold_weights(lt, lse_c, &at, &ac, &lnew);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                oacc[0][e] = fold_value(ot[0][e], oacc[0][e], at, ac);
-                oacc[1][e] = fold_value(ot[1][e], oacc[1][e], at, ac);
-            }
-            l_tot2 = lnew;
-        } else if constexpr (MODE == 3) {
             float at, ac, lnew;
             fold_weights(l_tot2, lse_c, &at, &ac, &lnew);
 #pragma unroll
@@ -762,9 +717,6 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
         }
         softmax(sc);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE == 1) {
-            if (nkt > CT) fetch_part(0, pre, lpre);
-        }
         pv((nkt - 1) & 1);
     };
     if (in_a) last(sa); else last(sb);
@@ -773,14 +725,28 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     if (q_ok) {
         const size_t row = (size_t)b * p.m_max + qrow;
         const int clast = (nkt - 1) / CT;          // split mode: the workgroup's last chunk is parked like the others
-        float* op = MODE == 2 ? p.part_o + ((size_t)clast * p.batch * p.m_max + row) * (p.heads * D) + head * D
-                              : p.out + row * p.ldo + head * D;
+        if (HI && MODE == 0 && p.out16) {          // fp16 context (what the consuming GEMM would round it to while staging)
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            _Float16* o16 = p.out16 + row * p.ldo16 + head * D;
 #pragma unroll
-        for (int dn = 0; dn < 2; ++dn)
+            for (int dn = 0; dn < 2; ++dn)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) =
-                    make_float4(oacc[dn][4 * g + 0], oacc[dn][4 * g + 1], oacc[dn][4 * g + 2], oacc[dn][4 * g + 3]);
+                for (int g = 0; g < 4; ++g) {
+                    half4v hv;
+                    hv[0] = (_Float16)oacc[dn][4 * g + 0]; hv[1] = (_Float16)oacc[dn][4 * g + 1];
+                    hv[2] = (_Float16)oacc[dn][4 * g + 2]; hv[3] = (_Float16)oacc[dn][4 * g + 3];
+                    *reinterpret_cast<half4v*>(o16 + dn * 32 + 8 * g + 4 * h) = hv;
+                }
+        } else {
+            float* op = MODE == 2 ? p.part_o + ((size_t)clast * p.batch * p.m_max + row) * (p.heads * D) + head * D
+                                  : p.out + row * p.ldo + head * D;
+#pragma unroll
+            for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) =
+                        make_float4(oacc[dn][4 * g + 0], oacc[dn][4 * g + 1], oacc[dn][4 * g + 2], oacc[dn][4 * g + 3]);
+        }
         if (h == 0) {
             const size_t li = ((size_t)b * p.heads + head) * p.m_max + qrow;
             if (MODE == 2) p.part_l[(size_t)((nkt - 1) / CT) * p.batch * p.heads * p.m_max + li] = l_tot2;
@@ -1065,7 +1031,25 @@ extern "C" int pram_attention_x3_is_split(int batch, int heads, int m_max, int n
 /* MFMA instructions (v_mfma_f32_32x32x16_f16) the kernel pram_attention_x3_f32 launches for n_max keys issues per 64-key tile and
    32-query wave; a single-product fp16 attention needs 16 (8 for K Q^T, 8 for P V).  40 = three products for the scores, two
    for P V (probabilities as one fp16); 48 = three and three (below 1024 keys).  bench.py prices its roofline with this. */
-extern "C" int pram_attention_x3_mfma_per_tile(int n_max) { return n_max < 1024 ? 48 : 40; }
+static int g_p_split = -1;
+static bool p_split_always() {
+    if (g_p_split < 0) {
+        const char* e = getenv("PRAM_ATTN_P");      // "split" / "fp16": see pram_attention_x3_set_p_split
+        g_p_split = (e && e[0] == 'f') ? 0 : 1;
+    }
+    return g_p_split != 0;
+}
+
+/* How the probabilities enter P V from 1024 keys on (below, always split): 1 = as two fp16 parts like every other operand (three
+   MFMAs per product, 48 per tile: the default), 0 = as ONE fp16 (two MFMAs, 40 per tile: ~15 % less attention time, but the
+   2^-12 rounding of every probability shows: SegNetViT logits 7e-4 from the fp32 oracle instead of 4e-5 on the synthetic token
+   sets of tests/, 0.15 % of the landmark arg-maxes flipped).  Process-wide; negative = query.  Returns the value in force. */
+extern "C" int pram_attention_x3_set_p_split(int split) {
+    if (split >= 0) g_p_split = split ? 1 : 0;
+    return p_split_always() ? 1 : 0;
+}
+
+extern "C" int pram_attention_x3_mfma_per_tile(int n_max) { return (n_max < 1024 || p_split_always()) ? 48 : 40; }
 
 /* Split-fp16 flash attention.  q / k: row-major planes written by pram_linear_x3_f32 (value * 16 = hi + lo; ld* in halves,
    16-byte aligned rows and head offsets); vt: the V^T planes of pram_attention_x3_vt for the KEY side ([batch][heads][64][tv],
@@ -1093,33 +1077,32 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
             hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0>), grid, blk, 0, st, p);
             return pram_launch_status("pram_attention_x3_f32");
         }
+        const bool psplit = p_split_always();      // probabilities as two fp16 parts (three MFMAs per P V product) also from 1024 keys on
+#define PRAM_LAUNCH_PIPE(MODE_, GRID_)                                                                           \
+    do {                                                                                                         \
+        if (psplit) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, MODE_>), GRID_, blk, 0, st, p);    \
+        else hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, MODE_>), GRID_, blk, 0, st, p);          \
+    } while (0)
         const size_t need = x3_ws_bytes(batch, heads, m_max, n_max);
-        static const char* force = getenv("PRAM_ATTN_MODE");      // profiling only: 0 = the unchunked kernel (different last bits), 1 / 2 / 3
+        static const char* force = getenv("PRAM_ATTN_MODE");      // profiling only: 0 = the unchunked kernel (different last bits), 1 = fused, 2 = split
         const int fm = force ? atoi(force) : -1;
-        if (fm == 0) {
-            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 0>), grid, blk, 0, st, p);
-            return pram_launch_status("pram_attention_x3_f32");
-        }
-        if (need == 0 && fm != 3) {      // one chunk per sequence: nothing is parked
-            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 1>), grid, blk, 0, st, p);
-            return pram_launch_status("pram_attention_x3_f32");
-        }
-        if (workspace == nullptr || workspace_bytes < need || fm == 3) {      // no workspace: the fused kernel folds in registers (slower, same bits)
-            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 3>), grid, blk, 0, st, p);
-            return pram_launch_status("pram_attention_x3_f32");
-        }
         const int nchunks = cdiv(n_max, chunk_tiles() * BKV);
+        if (fm == 0 || (nchunks < 2 && fm != 1)) {      // one chunk per sequence: the walk is the unchunked kernel's (a fold from (0, -inf) is exact)
+            PRAM_LAUNCH_PIPE(0, grid);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
+        int groups = (workspace == nullptr || workspace_bytes < need || need == 0) ? 1 : x3_split_groups(batch, heads, m_max, n_max);
+        if (fm == 2 && groups < 2 && workspace != nullptr && need != 0 && workspace_bytes >= need) groups = nchunks;
+        if (groups < 2 || fm == 1 || fm == 3) {          // fused: the workgroup folds its chunks in registers (no workspace needed)
+            PRAM_LAUNCH_PIPE(1, grid);
+            return pram_launch_status("pram_attention_x3_f32");
+        }
         p.part_o = (float*)workspace;
         p.part_l = p.part_o + (size_t)nchunks * batch * m_max * heads * D;
-        int groups = x3_split_groups(batch, heads, m_max, n_max);
-        if (fm == 2 && groups < 2) groups = nchunks;
-        if (groups < 2 || fm == 1) {
-            hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 1>), grid, blk, 0, st, p);
-            return pram_launch_status("pram_attention_x3_f32");
-        }
         p.group_tiles = cdiv(nchunks, groups) * p.chunk_tiles;
         p.nsplit = cdiv(nchunks * p.chunk_tiles, p.group_tiles);
-        hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 2>), dim3(grid.x, p.nsplit), blk, 0, st, p);
+        PRAM_LAUNCH_PIPE(2, dim3(grid.x, p.nsplit));
+#undef PRAM_LAUNCH_PIPE
         const long long rows = (long long)batch * m_max * heads;
         hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
@@ -1157,4 +1140,21 @@ extern "C" int pram_attention_h16t_f32(const void* q16, int ldq, const void* k16
             ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f, 1, 0, 0, nullptr, nullptr};
     hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_h16t_f32");
+}
+
+/* pram_attention_h16t_f32 with the context written as fp16 [batch * m_max][ldo16] (ldo16 % 4 == 0): the operand format of the
+   fp16 path's next GEMM (pram_linear_f16_ssq_h16) — the same values that GEMM would round the fp32 context to while staging it. */
+extern "C" int pram_attention_h16t_h16(const void* q16, int ldq, const void* k16, int ldk, const void* vt16, void* out16, int ldo16,
+                                       float* lse2, const int* q_lens, const int* k_lens, int batch, int heads, int m_max,
+                                       int n_max, float scale, int kv_shift, void* stream) {
+    PRAM_REQUIRE(q16 && k16 && vt16 && out16, "pram_attention_h16t_h16: null pointer");
+    PRAM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo16 % 4 == 0, "pram_attention_h16t_h16: ld of the fp16 operands must be a multiple of 8 (output: 4)");
+    PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_h16t_h16: bad sizes");
+    if (batch == 0 || m_max == 0) return PRAM_OK;
+    PRAM_REQUIRE(n_max > 0, "pram_attention_h16t_h16: empty key set");
+    ArgsX p{(const _Float16*)q16, nullptr, (const _Float16*)k16, nullptr, (const _Float16*)vt16, nullptr, nullptr, lse2, q_lens, k_lens,
+            ldq, ldk, cdiv(n_max, 64) * 64, 0, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f, 1, 0, 0, nullptr, nullptr,
+            (_Float16*)out16, ldo16};
+    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return pram_launch_status("pram_attention_h16t_h16");
 }

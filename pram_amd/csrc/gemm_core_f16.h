@@ -36,9 +36,26 @@ __device__ __forceinline__ int swz(int slot, int row) { return slot ^ ((row >> 1
 
 // ALoad(p, kt) -> raw float4 A[row = tid/16 + 16p][kt*64 + (tid%16)*4 ..+3];  AOk(p, kt) its predicate
 // BLoad(p, kt) -> raw uint4  W[col = tid/8 + 32p][kt*64 + (tid%8)*8 ..+7] (fp16); BOk(p, kt) its predicate
+// AXf(v, p, kt): optional transform of a staged A quad before it is rounded to fp16 (the LayerNorm + GELU of an MLP's hidden layer
+// on its way into the second GEMM, linear.hip); NoXform16 compiles to nothing.
+struct NoXform16 {
+    __device__ __forceinline__ void operator()(float4&, int, int) const {}
+};
+
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         f32x16 (&acc)[MI][2], AXf& axf);
+
 template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
 __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
                                          f32x16 (&acc)[MI][2]) {
+    NoXform16 none;
+    mainloop<MI, WN>(s, adv, la, oka, lb, okb, nk, acc, none);
+}
+
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         f32x16 (&acc)[MI][2], AXf& axf) {
     using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -62,6 +79,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, A
             const int row = arow + 16 * p;
             float4 v = ra[p];
             if (!oka(p, kt)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            else axf(v, p, kt);
             half4 hv;
             hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
             *reinterpret_cast<half4*>(&s.a[buf][row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4]) = hv;

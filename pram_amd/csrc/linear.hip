@@ -42,6 +42,7 @@ struct LinArgs {
     //   ln_ssq / ln_parts / ln_gamma / ln_beta / ln_eps (second GEMM, in): its A operand is GELU(a * rstd * gamma + beta), applied
     //     while the operand is staged; rstd = 1 / sqrt(sum_p ln_ssq[p][row] / K + eps).
     float* row_ssq;
+    int a0_f16, a1_f16;      // fp16 MFMA path: the A segment is fp16 in HBM (a0 / a1 point at halves, lda in halves) instead of fp32
     const float* ln_ssq; int ln_parts; const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
 
@@ -66,12 +67,12 @@ __device__ __forceinline__ float gelu_erf(float t) {
 
 // The A-operand transform of the second GEMM of an MLP tail (gemm_core_x3.h::mainloop, AXf): v = GELU(v * rstd[row] * gamma + beta)
 // on four consecutive k of row slot p.  gamma | beta live in LDS (gb: K floats each); rstd per row slot is computed once per thread.
-template <int PA>
+template <int PA, int BKC = 32>
 struct LnGeluXf {
-    const float* gb; int K; int kq;      // kq = this thread's float4 column inside a 32-deep chunk
+    const float* gb; int K; int kq;      // kq = this thread's float4 column inside a BKC-deep chunk
     float rstd[PA];
     __device__ __forceinline__ void operator()(float4& v, int p, int kt) const {
-        const int k = kt * 32 + kq * 4;
+        const int k = kt * BKC + kq * 4;
         const float4 g = *reinterpret_cast<const float4*>(gb + k);
         const float4 b = *reinterpret_cast<const float4*>(gb + K + k);
         const float rs = rstd[p];
@@ -249,9 +250,11 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                     }
                     const size_t d0 = (drow + r) * p.vt_tv + pos0 + 16 * g, d1 = (drow + 32 + r) * p.vt_tv + pos0 + 16 * g;
                     *reinterpret_cast<half8v*>(vh + d0) = h0;
-                    *reinterpret_cast<half8v*>(vl + d0) = l0;
                     *reinterpret_cast<half8v*>(vh + d1) = h1;
-                    *reinterpret_cast<half8v*>(vl + d1) = l1;
+                    if (vl) {      // the single-product path carries one plane
+                        *reinterpret_cast<half8v*>(vl + d0) = l0;
+                        *reinterpret_cast<half8v*>(vl + d1) = l1;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -387,12 +390,14 @@ __global__ __launch_bounds__(gemm::NT, (gemm::Cfg<MI, WN, BKT>::WAVES)) void lin
 }
 
 // fp16-operand variant (BASELINE C5 "fp16 MFMA path"): w16 is the weight matrix pre-converted to fp16.
-template <int MI, int WN>
+// LNA: the A operand (fp16 hidden layer of an MLP tail, centred) is normalised and GELU-ed while it is staged (LnGeluXf)
+template <int MI, int WN, bool LNA = false>
 __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, const _Float16* __restrict__ w16) {
     using namespace gemm16;
     using C = Cfg<MI, WN>;
     constexpr int BM = C::BM, BN = C::BN;
     __shared__ Smem<MI, WN> smem;
+    __shared__ __attribute__((aligned(16))) float lngb[LNA ? 2 * 1024 : 4];
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n, tm = id / p.tiles_n;
@@ -405,6 +410,13 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
         const int rc = min(row0 + arow + 16 * pp, mlast);
         const int kc = min(kt * BK + akq * 4, K - 4);
         const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 64 == 0
+        if (second ? p.a1_f16 : p.a0_f16) {                            // fp16 segment (wave-uniform): four halves, widened losslessly
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            const _Float16* src = second ? (reinterpret_cast<const _Float16*>(p.a1) + (size_t)rc * p.lda1 + (kc - p.k0))
+                                         : (reinterpret_cast<const _Float16*>(p.a0) + (size_t)rc * p.lda0 + kc);
+            const half4v hv = *reinterpret_cast<const half4v*>(src);
+            return make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+        }
         const float* src = second ? (p.a1 + (size_t)rc * p.lda1 + (kc - p.k0)) : (p.a0 + (size_t)rc * p.lda0 + kc);
         return *reinterpret_cast<const float4*>(src);
     };
@@ -417,7 +429,17 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 32 * pp) < p.n && (kt * BK + bsl * 8) < K; };
     auto adv = [](int) {};
     f32x16 acc[MI][2];
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+    if constexpr (LNA) {
+        for (int i = tid; i < K; i += NT) { lngb[i] = p.ln_gamma[i]; lngb[K + i] = p.ln_beta[i]; }
+        LnGeluXf<C::PA, BK> xf;
+        xf.gb = lngb; xf.K = K; xf.kq = akq;
+#pragma unroll
+        for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = (row0 + arow + 16 * pp) < p.m ? ln_rstd(p, row0 + arow + 16 * pp, K) : 0.f;
+        __syncthreads();
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc, xf);
+    } else {
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
+    }
     linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
 }
 
@@ -739,6 +761,12 @@ void launch_linear_f16_t(LinArgs& p, const _Float16* w16, hipStream_t st) {
     using C = gemm16::Cfg<MI, WN>;
     p.tiles_m = cdiv(p.m, C::BM);
     p.tiles_n = cdiv(p.n, C::BN);
+    if constexpr (WN == 2) {
+        if (p.ln_ssq) {
+            hipLaunchKernelGGL((linear_f16_kernel<MI, WN, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemm16::NT), 0, st, p, w16);
+            return;
+        }
+    }
     hipLaunchKernelGGL((linear_f16_kernel<MI, WN>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemm16::NT), 0, st, p, w16);
 }
 
@@ -1134,4 +1162,75 @@ extern "C" int pram_fourier_encoding_f32(const float* kpts, const float* wr, flo
     hipLaunchKernelGGL(fourier_kernel, dim3(cdiv(rows * 32, 256)), dim3(256), 0, (hipStream_t)stream, kpts, wr, cx, cy,
                        scale, cos_out, sin_out, rows);
     return pram_launch_status("pram_fourier_encoding_f32");
+}
+
+/* ---- fp16 MFMA path (BASELINE C5) with fp16 intermediates in HBM: the values a consuming GEMM would round to fp16 while staging
+   them are rounded where they are produced instead — q / k / v, the attention context and the MLP's hidden layer travel as 2 bytes
+   per element, the residual stream stays fp32.  Same results as the fp32-intermediate form except for the hidden layer, which is
+   rounded before its LayerNorm instead of after its GELU (this path's own tolerance). */
+static int linear_f16_impl(const char* who, const float* a0, int lda0, int k0, int a0_f16, const float* a1, int lda1, int k1, int a1_f16,
+                           const void* w16, const float* bias, const float* residual, int ldr, float* out, int ldo, void* out16, int ldo16,
+                           const LnIo* ln, const VtOut* vt, const int* lens, int m, int n, int flags, const float* rot_cos,
+                           const float* rot_sin, int rot_cols, void* stream) {
+    PRAM_REQUIRE(a0 && w16 && (out || out16), "%s: null pointer", who);
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "%s: bad sizes", who);
+    PRAM_REQUIRE((k0 + k1) % 8 == 0 && lda0 % 4 == 0 && (k1 == 0 || (a1 && k0 % gemm16::BK == 0 && lda1 % 4 == 0)), "%s: K %% 8, lda %% 4, concat needs k0 %% 64 == 0", who);
+    if (flags & PRAM_LIN_ROTARY) PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "%s: rotary needs cos/sin and rot_cols %% 64 == 0", who);
+    if (m == 0) return PRAM_OK;
+    LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, 1.0f, flags, rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out16, ldo16};
+    p.a0_f16 = a0_f16;
+    p.a1_f16 = a1_f16;
+    if (ln) {
+        p.row_ssq = ln->ssq_out;
+        if (ln->ssq_in) {
+            PRAM_REQUIRE(ln->gamma && ln->beta && ln->parts > 0 && k1 == 0 && k0 % 64 == 0 && k0 <= 1024 && n > 64, "%s: needs gamma / beta / parts, one input segment, K %% 64 == 0, K <= 1024, n > 64", who);
+            p.ln_ssq = ln->ssq_in; p.ln_parts = ln->parts; p.ln_gamma = ln->gamma; p.ln_beta = ln->beta; p.ln_eps = ln->eps;
+        }
+    }
+    if (vt) {
+        PRAM_REQUIRE(vt->hi && out16 && vt->t_seq > 0 && vt->t_seq % 64 == 0 && m % vt->t_seq == 0 && vt->heads > 0 && vt->col0 % 64 == 0 &&
+                     n == vt->col0 + vt->heads * 64 && ldo16 >= vt->col0, "%s: the value heads must be the last heads * 64 columns, sequences a multiple of 64 tokens", who);
+        p.vt_hi = vt->hi; p.vt_lo = nullptr; p.vt_col0 = vt->col0; p.vt_heads = vt->heads; p.vt_t = vt->t_seq; p.vt_tv = vt->t_seq;
+        p.out16_scale = 1.0f;
+        p.lens = lens;      // only the V^T epilogue looks at it (zeros beyond a sequence's length); the fp16 GEMM computes every row
+        p.t_pad = vt->t_seq;
+    }
+    int mi, wn;
+    gemm::choose_tile(m, n, &mi, &wn);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* w = (const _Float16*)w16;
+    if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
+    else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
+    return pram_launch_status(who);
+}
+
+/* q | k | v projection of an attention block on the fp16 path: columns [0, vt_col0) as fp16 row-major [m][ldo16], the value heads as
+   the transposed key-permuted fp16 values [m / t_seq][heads][64][t_seq] pram_attention_h16t_* reads (zeros beyond lens[s]). */
+extern "C" int pram_linear_f16_qkv_h16(const float* a0, int lda0, int k0, const void* w16, const float* bias, void* out16, int ldo16, void* vt16,
+                                       int vt_col0, int heads, int t_seq, int m, int n, int flags, const float* rot_cos, const float* rot_sin,
+                                       int rot_cols, const int* lens, void* stream) {
+    VtOut vt{vt16, nullptr, vt_col0, heads, t_seq};
+    return linear_f16_impl("pram_linear_f16_qkv_h16", a0, lda0, k0, 0, nullptr, 0, 0, 0, w16, bias, nullptr, 0, nullptr, 0, out16, ldo16, nullptr, &vt, lens,
+                           m, n, flags, rot_cos, rot_sin, rot_cols, stream);
+}
+
+/* MLP tail on the fp16 path, first GEMM: [a0 (fp32) | a1 (fp16, lda1 in halves)] w^T + bias with host-centred weights -> the hidden
+   layer as fp16 [m][ldo16] and its rows' sums of squares (taken from the fp32 values), parts = ceil(n / 64). */
+extern "C" int pram_linear_f16_ssq_h16(const float* a0, int lda0, int k0, const void* a1_16, int lda1, int k1, const void* w16, const float* bias,
+                                       void* out16, int ldo16, float* row_ssq, int m, int n, void* stream) {
+    PRAM_REQUIRE(row_ssq && out16, "pram_linear_f16_ssq_h16: null pointer");
+    LnIo ln{row_ssq, nullptr, 0, nullptr, nullptr, 0.f};
+    return linear_f16_impl("pram_linear_f16_ssq_h16", a0, lda0, k0, 0, reinterpret_cast<const float*>(a1_16), lda1, k1, 1, w16, bias, nullptr, 0, nullptr, 0,
+                           out16, ldo16, &ln, nullptr, nullptr, m, n, 0, nullptr, nullptr, 0, stream);
+}
+
+/* MLP tail on the fp16 path, second GEMM: out (fp32) = GELU(LayerNorm(hidden16)) w^T + bias + residual, LayerNorm + GELU applied
+   while the fp16 hidden layer is staged (as pram_linear_x3_lngelu_f32). */
+extern "C" int pram_linear_f16_lngelu_f32(const void* hidden16, int ldh, int k, const void* w16, const float* bias, const float* residual, int ldr,
+                                          float* out, int ldo, int m, int n, const float* ln_ssq, int parts, const float* gamma,
+                                          const float* beta, float eps, void* stream) {
+    PRAM_REQUIRE(ln_ssq && out, "pram_linear_f16_lngelu_f32: null pointer");
+    LnIo ln{nullptr, ln_ssq, parts, gamma, beta, eps};
+    return linear_f16_impl("pram_linear_f16_lngelu_f32", reinterpret_cast<const float*>(hidden16), ldh, k, 1, nullptr, 0, 0, 0, w16, bias, residual, ldr, out, ldo,
+                           nullptr, 0, &ln, nullptr, nullptr, m, n, 0, nullptr, nullptr, 0, stream);
 }

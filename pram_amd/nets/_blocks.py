@@ -84,6 +84,11 @@ def _half_path() -> bool:
 
 import os as _os
 FUSED_MLP = _os.environ.get("PRAM_FUSED_MLP", "1") != "0"    # LayerNorm + GELU inside the second GEMM of the MLP tail (0: three kernels)
+# fp16 path: q / k / v, the attention context and the MLP's hidden layer travel as fp16 in HBM (pram_linear_f16_qkv_h16,
+# pram_attention_h16t_h16, pram_linear_f16_ssq_h16, pram_linear_f16_lngelu_f32).  OFF by default: same accuracy class, 45 % fewer
+# bytes per block — and 3 % SLOWER at the C5 shape (347.6 vs 359.1 q/s): the 128 x 128 fp16 GEMM is bound by the latency of its
+# register staging, not by bytes, and the LayerNorm + GELU transform lands on its critical path.
+F16_ACT = _os.environ.get("PRAM_F16_ACT", "0") == "1"
 FUSED_VT = _os.environ.get("PRAM_FUSED_VT", "1") != "0"      # the projection epilogue writes the V^T planes (0: separate transpose kernel)
 
 
@@ -127,6 +132,12 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
         return _mlp_tail(x, ops.attention_x3(q3, k3, v3, S, HEADS, T, T, scale, lens, lens), p, lens, T)
     if _half_path() and not want_colmean:
         # fp16 path: the projection writes q | k | v as fp16 only (what the fp16 attention would round them to anyway)
+        if F16_ACT and T % 64 == 0:
+            # fp16 intermediates in HBM: the projection writes q | k as fp16 rows and v transposed, the attention writes an fp16
+            # context, the MLP's hidden layer travels as fp16 and is normalised inside the second GEMM (ops.mlp_tail_f16)
+            h16, vt = ops.linear_qkv_h16(x, p["qkv_w"], p["qkv_b"], HEADS, T, rotary=(cos, sin, 2 * HEADS * DH), lens=lens)
+            ctx16 = ops.attention_h16t(h16[:, :hid], h16[:, hid:2 * hid], vt, S, HEADS, T, T, scale, lens, lens, out16=True)
+            return ops.mlp_tail_f16(x, ctx16, p["mlp0_w"], p["mlp0_b"], p["mlp.1.weight"], p["mlp.1.bias"], p["mlp.3.weight"], p["mlp.3.bias"])
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), half_copy="only")
         vt = ops.value_t16(h16[:, 2 * hid:], S, HEADS, T, lens)
         ctx = ops.attention_h16t(h16[:, :hid], h16[:, hid:2 * hid], vt, S, HEADS, T, T, scale, lens, lens)
@@ -160,6 +171,10 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
             return _mlp_tail(x, ctx, p, lens, T), col
         return _mlp_tail(x, ops.attention_x3(qk3, qk3, v3, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B), p, lens, T)
     if _half_path() and not want_colmean:
+        if F16_ACT and T % 64 == 0:
+            qk16, vt = ops.linear_qkv_h16(x, p["qkv_w"], p["qkv_b"], HEADS, T, lens=lens)
+            ctx16 = ops.attention_h16t(qk16, qk16, vt, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B, out16=True)
+            return ops.mlp_tail_f16(x, ctx16, p["mlp0_w"], p["mlp0_b"], p["mlp.1.weight"], p["mlp.1.bias"], p["mlp.3.weight"], p["mlp.3.bias"])
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], half_copy="only")
         qk16, v16 = h16[:, :hid], h16[:, hid:]
         vt = ops.value_t16(v16, 2 * B, HEADS, T, lens)

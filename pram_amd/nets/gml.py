@@ -177,10 +177,13 @@ class GML(blk.PackedCache, nn.Module):
             x = blk.cross_block(x, P["cross"][i], B, T, lens)
         d = x.shape[-1]
         ldc = (T + 3) // 4 * 4
-        if blk._split_path() and d % 32 == 0:
+        if (blk._split_path() or blk._half_path()) and d % 32 == 0:
             # the matching descriptors leave the projection as split planes and meet on the fp16 matrix pipe as well
             # ragged like everything upstream: rows beyond a set's size hold whatever the (ragged) producers left there
-            _, pl = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, split_out="only", lens=lens, t_pad=T)
+            # (fp16 path too: the score matrix feeds a Sinkhorn whose plan is fp32 — the split kernels are both faster than the
+            # exact-fp32 ones and more accurate than a single fp16 product)
+            _, pl = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, split_out="only", lens=lens, t_pad=T,
+                               precision="x3")
             dist = ops.bgemm_nt_planes((pl[0][:B * T], pl[1][:B * T]), (pl[0][B * T:], pl[1][B * T:]), B, T, T, ldc=ldc)
         else:
             md = ops.linear(x, P["out_w"][nI - 1], P["out_b"][nI - 1], alpha=1.0 / d ** .25, lens=lens, t_pad=T).view(2 * B, T, d)

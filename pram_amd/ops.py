@@ -178,6 +178,52 @@ def mlp_tail(x: torch.Tensor, w0c: torch.Tensor, b0c: torch.Tensor, gamma: torch
     return out
 
 
+def linear_qkv_h16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, t_seq: int,
+                   rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, lens: Optional[torch.Tensor] = None):
+    """The q | k | v (or qk | v) projection on the fp16 path with fp16 outputs: -> (fp16 [m, n - heads * 64] q / k columns,
+    vt16 = the transposed key-permuted fp16 values [m / t_seq, heads, 64, t_seq] of attention_h16t).  t_seq % 64 == 0."""
+    L = _lib.load()
+    x = x.contiguous()
+    m, k0 = _rows2d(x, "x")
+    n = w.shape[0]
+    col0 = n - heads * 64
+    assert t_seq % 64 == 0 and m % t_seq == 0 and k0 % 64 == 0 and col0 > 0 and col0 % 64 == 0
+    out16 = torch.empty(m, col0, device=x.device, dtype=torch.float16)
+    vt = torch.empty(m // t_seq, heads, 64, t_seq, device=x.device, dtype=torch.float16)
+    flags, rc, rs, rcols = 0, None, None, 0
+    if rotary is not None:
+        rc, rs, rcols = rotary
+        flags = 1
+    if m:
+        _lib.check(L.pram_linear_f16_qkv_h16(_p(x), k0, k0, _p(_w16(w.contiguous())), _p(bias), _p(out16), col0, _p(vt), col0, heads, t_seq, m, n,
+                                             flags, _p(rc), _p(rs), int(rcols), _p(lens), _st()), "pram_linear_f16_qkv_h16")
+    return out16, vt
+
+
+def mlp_tail_f16(x: torch.Tensor, ctx16: torch.Tensor, w0c: torch.Tensor, b0c: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                 w3: torch.Tensor, b3: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """x + Linear(w3)(GELU(LayerNorm(Linear(w0c)([x | ctx])))) on the fp16 MFMA path with fp16 intermediates: x fp32 [m, k0] (the
+    residual stream), ctx16 fp16 [m, k1] (attention_h16t(out16=True)); the hidden layer travels as fp16."""
+    L = _lib.load()
+    x = x.contiguous()
+    m, k0 = _rows2d(x, "x")
+    assert ctx16.dtype == torch.float16 and ctx16.is_contiguous() and ctx16.shape[0] == m
+    k1 = ctx16.shape[1]
+    hid, n = w0c.shape[0], w3.shape[0]
+    assert k0 % 64 == 0 and k1 % 64 == 0 and hid % 64 == 0 and hid <= 1024 and n > 64 and w0c.shape[1] == k0 + k1 and w3.shape[1] == hid and n == k0
+    out = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    if m == 0:
+        return out
+    parts = (hid + 63) // 64
+    h16 = torch.empty(m, hid, device=x.device, dtype=torch.float16)
+    ssq = torch.empty(parts, m, device=x.device, dtype=torch.float32)
+    _lib.check(L.pram_linear_f16_ssq_h16(_p(x), k0, k0, _p(ctx16), k1, k1, _p(_w16(w0c.contiguous())), _p(b0c), _p(h16), hid, _p(ssq), m, hid, _st()),
+               "pram_linear_f16_ssq_h16")
+    _lib.check(L.pram_linear_f16_lngelu_f32(_p(h16), hid, hid, _p(_w16(w3.contiguous())), _p(b3), _p(x), n, _p(out), n, m, n, _p(ssq), parts,
+                                            _p(gamma), _p(beta), float(eps), _st()), "pram_linear_f16_lngelu_f32")
+    return out
+
+
 def center_linear(w: torch.Tensor, b: torch.Tensor):
     """(w - mean over the outputs, b - mean) in fp64 -> fp32: a Linear whose output is h - mean(h).  LayerNorm(h) only needs the
     centred values (it is invariant to the shift), so a Linear that feeds a LayerNorm can be centred once at pack time."""
@@ -593,7 +639,7 @@ def value_t16(v16: torch.Tensor, seqs: int, heads: int, t_max: int, lens: Option
 
 def attention_h16t(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: int, heads: int, m_max: int, n_max: int, scale: float,
                    q_lens: Optional[torch.Tensor] = None, k_lens: Optional[torch.Tensor] = None, want_lse: bool = False,
-                   out: Optional[torch.Tensor] = None, kv_shift: int = 0):
+                   out: Optional[torch.Tensor] = None, kv_shift: int = 0, out16: bool = False):
     """The fp16 path's attention on the software-pipelined kernel: fp16 q / k (2-D views), vt = value_t16(...) of the key side.
     One fp16 MFMA per product, probabilities rounded to fp16 (tolerance of the fp16 path)."""
     L = _lib.load()
@@ -601,14 +647,19 @@ def attention_h16t(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, batch: in
         assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
     assert vt.is_contiguous() and vt.dtype == torch.float16
     if out is None:
-        out = torch.empty(batch * m_max, heads * 64, device=q.device, dtype=torch.float32)
+        out = torch.empty(batch * m_max, heads * 64, device=q.device, dtype=torch.float16 if out16 else torch.float32)
     lse = torch.empty(batch, heads, m_max, device=q.device, dtype=torch.float32) if want_lse else None
     probe = attention_probe
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.pram_attention_h16t_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), _p(out), out.stride(0), _p(lse), _p(q_lens),
-                                         _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_h16t_f32")
+    if out16:      # the context as fp16: the operand format of the fp16 path's next GEMM
+        assert out.dtype == torch.float16
+        _lib.check(L.pram_attention_h16t_h16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), _p(out), out.stride(0), _p(lse), _p(q_lens),
+                                             _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_h16t_h16")
+    else:
+        _lib.check(L.pram_attention_h16t_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), _p(out), out.stride(0), _p(lse), _p(q_lens),
+                                             _p(k_lens), batch, heads, m_max, n_max, float(scale), int(kv_shift), _st()), "pram_attention_h16t_f32")
     if probe is not None:
         e1.record()
         kl = k_lens if (k_lens is None or not kv_shift) else torch.roll(k_lens, -kv_shift)
@@ -648,8 +699,8 @@ def attention_x3(q, k, vt, batch: int, heads: int, m_max: int, n_max: int, scale
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    # from 1024 keys on the kernel parks its key chunks in a workspace; under-filled launches (one or two query frames) run the
-    # chunks as a grid dimension: same bits, shorter serial walk.  attention_split = False (tests): no workspace -> always fused.
+    # from 1024 keys on the keys are reduced in chunks; under-filled launches (one or two query frames) run the chunks as a grid
+    # dimension through a workspace: same bits, shorter serial walk.  attention_split = False (tests): no workspace -> always fused.
     nb = int(L.pram_attention_x3_workspace_bytes(batch, heads, m_max, n_max)) if attention_split else 0
     ws = _workspace(nb, q[0].device, "attention_x3") if nb else None
     _x3_status(q[0].device)

@@ -1,5 +1,5 @@
 """Timing of attention_x3 at the bench's launch shapes (warm), optionally under PRAM_ATTN_ABLATE / PRAM_ATTN_MODE (see
-attention_x3.hip: MODE 0 = the unchunked kernel, 1 = fused with parked key chunks, 2 = split, 3 = fused with the fold in registers).
+attention_x3.hip: MODE 0 = the unchunked kernel, 1 = fused (key chunks folded in registers), 2 = split).
     python profiles/tools/x3_attn_probe.py"""
 import os
 import sys

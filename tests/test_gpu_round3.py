@@ -155,6 +155,34 @@ def test_pipeline_guard_and_graph_replay(dev):
     assert torch.equal(got["prediction"], want) and not ops.x3_range_exceeded(dev)
 
 
+# ------------------------------------------------------------------------------------------------ probabilities in P V
+def test_default_path_logits_and_landmarks_over_several_token_sets(dev):
+    """SegNetViT at 2048 tokens on four synthetic token sets (flat attention: the case in which rounding every probability to ONE
+    fp16 shows): the default path keeps the logits within 1e-4 of the fp32 oracle and every landmark arg-max; the opt-in
+    one-fp16 mode (pram_attention_x3_set_p_split(0)) stays inside the 1e-3 bar but is an order of magnitude further out."""
+    from tests.test_gpu_configs import _segnet, _tokens
+    L = ops._lib.load()
+    assert L.pram_attention_x3_set_p_split(-1) == 1, "two-part probabilities are the default"
+    net = _segnet(dev, 113)
+    worst = {1: 0.0, 0: 0.0}
+    for idx in (0, 1, 2, 3):
+        desc, kp = _tokens(2048, idx=idx)
+        ref = R.segnetvit_forward(H.segnet_sd(113), desc, kp, (1, 3, 480, 640))
+        data = {"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)}
+        out = net(data)["prediction"].cpu()
+        d = float((out - ref).abs().max())
+        worst[1] = max(worst[1], d)
+        assert d < 1e-4 and bool((out.argmax(-1) == ref.argmax(-1)).all()), (idx, d)
+        try:
+            L.pram_attention_x3_set_p_split(0)
+            out1 = net(data)["prediction"].cpu()
+        finally:
+            L.pram_attention_x3_set_p_split(1)
+        worst[0] = max(worst[0], float((out1 - ref).abs().max()))
+    print(f"SegNetViT N=2048 nc113, 4 token sets: |logit - oracle| two-part P {worst[1]:.2e}, one-fp16 P {worst[0]:.2e}")
+    assert worst[0] < 1e-3
+
+
 # ------------------------------------------------------------------------------------------------ key-split attention
 @pytest.fixture
 def chunk_keys():
@@ -171,9 +199,9 @@ def chunk_keys():
 @pytest.mark.parametrize("shape", [(1, 2048, 2048, 512), (2, 1500, 1100, 512), (1, 2048, 2048, 1024), (1, 1024, 4096, 2048), (3, 640, 1030, 512),
                                    (1, 2048, 4096, 1024)])
 def test_attention_x3_split_equals_fused(dev, shape, chunk_keys):
-    """Under-filled launches run groups of key chunks as a second grid dimension + a fold kernel; fused launches park the same
-    chunks and fold them at the end (or, without a workspace, in registers): bit-identical outputs and log-sum-exps (so a padded
-    batch element still equals its B = 1 run), at every chunk size."""
+    """Under-filled launches run groups of key chunks as a second grid dimension + a fold kernel; fused launches fold the same
+    chunks in registers, in the same order: bit-identical outputs and log-sum-exps (so a padded batch element still equals its
+    B = 1 run), at every chunk size."""
     S, M, N, ck = shape
     chunk_keys(ck)
     T = max(M, N)
@@ -192,7 +220,7 @@ def test_attention_x3_split_equals_fused(dev, shape, chunk_keys):
         ops.attention_split = True
         o1, l1 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # split: chunks as a grid dimension
         L.pram_attention_x3_set_split_target(0)
-        o2, l2 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # fused, chunks parked in the workspace
+        o2, l2 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # fused (a workspace is offered, not used)
         ops.attention_split = False
         o3, l3 = ops.attention_x3(q3, k3, vt, S, 4, Tp, Tp, 0.125, ql, kl, want_lse=True)          # fused, no workspace
     finally:
@@ -215,6 +243,42 @@ def test_attention_x3_split_equals_fused(dev, shape, chunk_keys):
         want = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(m, 256)
         d = float((o1[s * Tp:s * Tp + m].double() - want).abs().max())
         assert d < 2e-4, (s, d)
+
+
+@pytest.mark.parametrize("p_split", [1, 0])
+def test_x3_attention_many_workgroups_every_mode(dev, chunk_keys, p_split):
+    """640 workgroups (two resident per CU, 2560 waves) x four 512-key chunks, repeated: every sequence against fp64 soft-max
+    attention, fused and split, with the probabilities as two fp16 parts and as one.  A fused variant that folded parked chunks
+    after the last tile failed exactly this launch on ~1 wave in 2500 (one output register, 16 lanes) and nothing smaller."""
+    S, T = 10, 2048
+    chunk_keys(512)
+    L = ops._lib.load()
+    x = W.normal(31, "mw/x", (S * T, 256), 1.0).to(dev)
+    wq = W.normal(31, "mw/w", (768, 256), 0.06).to(dev)
+    pl, vt = ops.linear_qkv_planes(x, wq, None, 4, T)
+    q3, k3 = (pl[0][:, :256], pl[1][:, :256]), (pl[0][:, 256:512], pl[1][:, 256:512])
+    _, plv = ops.linear(x, wq, None, split_out="only")
+    full = (plv[0].double() + plv[1].double()) / 16
+    want = torch.empty(S * T, 256, dtype=torch.float64, device=dev)
+    for s in range(S):
+        qq, kk, vv = (full[s * T:(s + 1) * T, c * 256:(c + 1) * 256].view(T, 4, 64).transpose(0, 1) for c in range(3))
+        want[s * T:(s + 1) * T] = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(T, 256)
+    prev = L.pram_attention_x3_set_p_split(-1)
+    try:
+        L.pram_attention_x3_set_p_split(p_split)
+        outs = []
+        for target in (0, 4096):          # 0: never split (fused); 4096: four key groups of one chunk each + the fold kernel
+            L.pram_attention_x3_set_split_target(target)
+            assert (L.pram_attention_x3_is_split(S, 4, T, T) > 1) == (target > 0)
+            for rep in range(12):
+                o = ops.attention_x3(q3, k3, vt, S, 4, T, T, 0.125)
+                d = float((o.double() - want).abs().max())
+                assert d < (2e-6 if p_split else 2e-4), (target, rep, d)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        L.pram_attention_x3_set_split_target(-1)
+        L.pram_attention_x3_set_p_split(prev)
 
 
 @pytest.mark.parametrize("ck", [512, 2048])
@@ -343,6 +407,32 @@ def test_erf_of_the_fused_gelu_against_erff(dev):
         worst = max(worst, float((got - want).abs().max()))
     print(f"fused GELU (fitted tail) vs fp64 GELU on [-9, 9]: max |d| = {worst:.2e}")
     assert worst < 3e-6          # split-fp16 identity products + fp32 LayerNorm arithmetic around a 1.5e-7 erf
+
+
+# ------------------------------------------------------------------------------------------------ fp16 path, fp16 intermediates
+def test_fp16_path_with_fp16_intermediates_keeps_its_accuracy_class(dev):
+    """PRAM_F16_ACT=1 (opt-in): q / k / v, the attention context and the MLP's hidden layer in fp16 in HBM — the values the
+    consuming kernels would round to fp16 anyway (the hidden layer: before its LayerNorm instead of after its GELU).  Same
+    accuracy class as the fp32-intermediate fp16 path: bars at 2 x the measured distances to the fp32 oracle."""
+    from pram_amd.nets import _blocks as blk
+    from tests.test_gpu_configs import _segnet, _tokens
+    desc, kp = _tokens(2048, idx=2)
+    ref = R.segnetvit_forward(H.segnet_sd(113), desc, kp, (1, 3, 480, 640))
+    net = _segnet(dev, 113).set_precision("f16")
+    data = {"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)}
+    saved = blk.F16_ACT
+    try:
+        out = {}
+        for act in (False, True):
+            blk.F16_ACT = act
+            out[act] = net(data)["prediction"].cpu()
+    finally:
+        blk.F16_ACT = saved
+        net.set_precision(None)
+    d_old, d_new = H.maxdiff(out[False], ref), H.maxdiff(out[True], ref)
+    agree = float((out[True].argmax(-1) == ref.argmax(-1)).float().mean())
+    print(f"fp16 path N=2048 nc113: |logit - oracle| fp32 intermediates {d_old:.3e}, fp16 intermediates {d_new:.3e}, argmax agreement {agree:.4f}")
+    assert d_new < 8e-2 and d_new < 2.0 * d_old + 1e-2 and agree >= 0.99
 
 
 # ------------------------------------------------------------------------------------------------ glue kernels

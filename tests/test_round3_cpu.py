@@ -103,7 +103,15 @@ def test_new_entry_points_are_declared_bound_and_exported():
         assert re.search(r"\b" + name + r"\s*\(", header), name
         assert name in _lib.exported_symbols() and hasattr(L, name), name
     assert L.pram_hip_version() >= 110
-    assert L.pram_attention_x3_mfma_per_tile(2048) == 40 and L.pram_attention_x3_mfma_per_tile(512) == 48
+    # probabilities as two fp16 parts by default (three MFMAs per P V product, 48 per tile); as one fp16: 40 from 1024 keys on
+    prev = L.pram_attention_x3_set_p_split(-1)
+    try:
+        assert L.pram_attention_x3_set_p_split(1) == 1
+        assert L.pram_attention_x3_mfma_per_tile(2048) == 48 and L.pram_attention_x3_mfma_per_tile(512) == 48
+        assert L.pram_attention_x3_set_p_split(0) == 0
+        assert L.pram_attention_x3_mfma_per_tile(2048) == 40 and L.pram_attention_x3_mfma_per_tile(512) == 48
+    finally:
+        L.pram_attention_x3_set_p_split(prev)
     assert L.pram_linear_x3_ssq_parts(1000, 512, 512) == 8 and L.pram_linear_x3_ssq_parts(1, 1024, 256) == 16
     # the key-chunk geometry (no GPU needed): one chunk per 2048 keys by default -> no workspace, no split at 2048 keys
     assert L.pram_attention_x3_set_chunk_keys(0) == 2048
