@@ -505,6 +505,9 @@ def main():
     ap.add_argument("--alt", default="auto", choices=["auto", "on", "off"],
                     help="also time, in the same run (3 steps each), AdaGML, the exact-fp32 path, the secondary 512 x 1024 matcher "
                          "shape and the one-query latency, and report them as 'alt' (auto: on for the default 1-GPU configuration)")
+    ap.add_argument("--attn-chunk-keys", type=int, default=None,
+                    help="keys per chunk of the split-fp16 attention (pram_attention_x3_set_chunk_keys; default: the library's 2048, "
+                         "512 with --latency so that one-frame launches split along the keys and fill the chip)")
     ap.add_argument("--precision", default=None, choices=["f32", "x3", "f16"],
                     help="MFMA path of the three matrix families: f32 = v_mfma_f32_32x32x2_f32 (exact fp32 products); "
                          "x3 = split-fp16, three v_mfma_f32_32x32x16_f16 per product (fp32-class accuracy, passes the fp32 "
@@ -549,6 +552,9 @@ def main():
     from pram_amd.pipeline import shard_range
     if args.precision:
         ops.set_precision(args.precision)
+    from pram_amd import _lib as _plib
+    chunk_keys = args.attn_chunk_keys if args.attn_chunk_keys is not None else (512 if args.latency else 0)
+    chunk_keys = int(_plib.load().pram_attention_x3_set_chunk_keys(int(chunk_keys)))      # 0 = query; process-wide, before the first launch
     if ops.attention_precision != ops.gemm_precision:
         raise SystemExit(f"bench.py: PRAM_GEMM_PRECISION={ops.gemm_precision} and PRAM_ATTENTION_PRECISION={ops.attention_precision} "
                          f"differ — the line reports ONE arithmetic (use --precision / PRAM_PRECISION)")
@@ -641,7 +647,7 @@ def main():
     if rank == 0 and world == 1 and want_alt:
         alt = {}
 
-        def alt_run(name, note, steps_=3, warm_=2, p_split=None, **kw):
+        def alt_run(name, note, steps_=3, warm_=2, p_split=None, chunk=None, **kw):
             cfg = dict(matcher_name=args.matcher, kpts=args.kpts, n_class=args.n_class, stages=args.stages, inflight=inflight,
                        use_graph=False, precision=None, ref_kpts=0, match_kpts=0)
             cfg.update(kw)
@@ -651,6 +657,9 @@ def main():
             saved_p = L.pram_attention_x3_set_p_split(-1)
             if p_split is not None:
                 L.pram_attention_x3_set_p_split(int(p_split))
+            saved_ck = L.pram_attention_x3_set_chunk_keys(0)
+            if chunk is not None:
+                L.pram_attention_x3_set_chunk_keys(int(chunk))
             try:
                 j = Job(dev, 0, 1, 0, Bq, **cfg)
                 t, _ = j.timed(steps_, warm_, sync_all)
@@ -663,6 +672,7 @@ def main():
                 alt[name] = {"error": f"{type(e).__name__}: {e}"[:300], "what": note}
             finally:
                 L.pram_attention_x3_set_p_split(saved_p)
+                L.pram_attention_x3_set_chunk_keys(saved_ck)
             torch.cuda.empty_cache()
 
         alt_run("attention_p_one_fp16", "same step with the soft-max probabilities entering P.V as ONE fp16 (pram_attention_x3_set_p_split(0): two MFMAs per "
@@ -671,8 +681,8 @@ def main():
         alt_run("exact_f32", "same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)", precision="f32")
         alt_run("gml_512x1024", "secondary matcher shape of SURVEY 8(d): the 512 best keypoints of a query against 1024-keypoint reference sets",
                 ref_kpts=1024, match_kpts=512)
-        alt_run("latency_b1", "one query per step, one step at a time, captured hipGraph replayed (the reference's online loop); ms_per_step = per-query latency",
-                steps_=30, warm_=10, B=1, inflight=1, use_graph=True)
+        alt_run("latency_b1", "one query per step, one step at a time, captured hipGraph replayed (the reference's online loop), 512-key attention chunks "
+                "(= python bench.py --latency); ms_per_step = per-query latency", steps_=30, warm_=10, B=1, inflight=1, use_graph=True, chunk=512)
 
     if rank == 0:
         total_q = total_per_step * steps
@@ -690,7 +700,7 @@ def main():
                                    f"stages={args.stages}" + ("; latency mode: one query at a time" if args.latency else ""),
                        "precision": precision,
                        "queries_per_step": total_per_step, "queries_per_gpu_per_step": shard_sizes if job.uneven else B,
-                       "batches_in_flight_per_gpu": max(1, inflight), "hipgraph_replay": bool(use_graph),
+                       "batches_in_flight_per_gpu": max(1, inflight), "hipgraph_replay": bool(use_graph), "attention_chunk_keys": chunk_keys,
                        "frame": f"{W_IMG}x{H}", "keypoints": args.kpts,
                        "keypoints_found": counts[:4], "parallelism": f"query-sharded x{world}, one all-gather of result records",
                        "matches_last_step": n_matches, "matches_correct_last_step": n_correct},

@@ -6,15 +6,17 @@
 //     x * 16 = hi + lo,  hi = fp16(16 x),  lo = fp16(16 x - hi)
 // and every product is three MFMAs accumulated in fp32 (gemm_core_x3.h has the error analysis):
 //     S^T = K_hi Q_hi + K_hi Q_lo + K_lo Q_hi            (= 256 K Q^T; the 1/256 rides in the softmax scale)
-//     O^T = V^T_hi P_hi + V^T_lo P_hi                     (P = fp16(2^14 exp2(...)), = 2^18 V^T P; two MFMAs: see the loop)
+//     O^T = V^T_hi P_hi + V^T_lo P_hi + V^T_hi P_lo       (P = 2^14 exp2(...) = P_hi + P_lo, = 2^18 V^T P)
 // The probabilities are scaled by 2^14 (an offset in the exponent argument: free) so that fp16 keeps 11 bits for every
-// probability above 2^-28 of the row maximum; the row sum accumulates the same rounded values, so scale and rounding
-// bias cancel in the normalisation.
+// probability above 2^-28 of the row maximum.  PSPLIT = false (pram_attention_x3_set_p_split(0), from 1024 keys on) drops the
+// P_lo product: P is then ONE fp16 whose rounding (2^-12 relative per probability) does not average out of flat attention —
+// the output is a small difference of large terms — and shows as 7e-4 on SegNetViT's logits against 4e-5; the row sum then
+// accumulates the same rounded values, so scale and rounding bias cancel in the normalisation.
 //
 // Register design as attention.hip / attention_f16.hip: everything transposed so that the query row is the lane
 // index in every accumulator (online-softmax state lane-local, P never leaves registers); K tile [key][d] and V tile
 // TRANSPOSED and key-permuted [d][pos(key)] in LDS so that both MFMA operands are single ds_read_b128s.
-// Per 64-key tile per wave: 40 MFMA x 32 cycles = 1280 matrix cycles (the f32-MFMA kernel: 8192).
+// Per 64-key tile per wave: 48 MFMA x 32 cycles = 1536 matrix cycles (40 / 1280 without the P_lo product; the f32-MFMA kernel: 8192).
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>

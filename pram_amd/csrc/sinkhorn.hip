@@ -14,6 +14,7 @@
 // torch.max(dim).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -104,62 +105,114 @@ __global__ __launch_bounds__(256) void sink_init_kernel(const float* __restrict_
 }
 
 // ---- one Sinkhorn iteration: u = r / (P v + eps), column partials of P^T u -----------------------
-template <int NV>
+// PF = rows a wave requests ahead.  A row is one dependent chain (load -> dot -> wave reduction -> u_i -> column accumulation) and a
+// one-pair launch is 32 workgroups with 16 rows per wave, so what matters there is that the row ahead is REALLY in flight.  It
+// was not in the first version (28 us per iteration at 2049 x 2049 = 0.6 TB/s; now 14 us): (a) loads under a per-lane predicate
+// sit in exec branches and the compiler waits with vmcnt(0) at the joins; (b) a store inside the loop (u_i) beside outstanding
+// loads forces vmcnt(0) — loads and stores return out of order with respect to each other on gfx9; (c) a loop the compiler takes
+// for divergent carries the row slots through copies, and a copy of a register a load is still writing is a wait; (d) v was
+// copied to LDS by a scalar loop: nine dependent round trips.  More rows ahead (PF = 2, 4) or one wave per workgroup on 128 CUs
+// measured the same or worse — what is left is the chain itself (six ds_bpermute steps and a division per row).  The rows of a
+// wave are reduced in the same order whatever PF is: the partial sums do not depend on it.
+template <int NV, int PF>
 __global__ __launch_bounds__(256) void sink_iter_kernel(const int* __restrict__ m_lens, const int* __restrict__ n_lens,
                                                         SinkWs w, int m_max, int n_max) {
     extern __shared__ __attribute__((aligned(16))) float sv[];
     const int b = blockIdx.y;
     const int m = m_lens ? m_lens[b] : m_max;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NTHR = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the row loop is wave-uniform
+    const int blk = blockIdx.x;
     const int ldw = w.ldw;
-    for (int j = tid; j < ldw; j += 256) sv[j] = w.v[(size_t)b * ldw + j];
+    {   // v -> LDS, zero-padded to NV * 256 (no column guard below); every load is out before the first is stored — written as a
+        // scalar loop this prologue was nine dependent round trips, half of the kernel at one pair
+        constexpr int NQ = (NV * 64 + NTHR - 1) / NTHR;
+        float4 q4[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) q4[t] = *reinterpret_cast<const float4*>(w.v + (size_t)b * ldw + min((tid + t * NTHR) * 4, ldw - 4));
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const int j = (tid + t * NTHR) * 4;
+            const float mk = j < ldw ? 1.f : 0.f;
+            if (j < NV * 256) *reinterpret_cast<float4*>(sv + j) = make_float4(q4[t].x * mk, q4[t].y * mk, q4[t].z * mk, q4[t].w * mk);
+        }
+    }
     __syncthreads();
     const int rows = m + 1;
     const int rpb = (rows + NBLK - 1) / NBLK;
-    const int rbeg = blockIdx.x * rpb;
+    const int rbeg = blk * rpb;
     const int rend = min(rows, rbeg + rpb);
     float4 cacc[NV];
 #pragma unroll
     for (int t = 0; t < NV; ++t) cacc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Pb = w.P + (size_t)b * (m_max + 1) * ldw;
-    // the next row of the wave is requested before the current one is reduced: a row is one dependent chain (load -> dot ->
-    // wave reduction -> u_i -> column accumulation), and without the prefetch every row pays a full memory round trip
-    float4 nx[NV];
+    float4 nx[PF][NV];
+    float ukeep = 0.f;
+    // every lane loads from a clamped address and the value is masked afterwards: a load under a per-lane predicate sits in its own
+    // exec branch and the compiler then waits with vmcnt(0) at the join — for the rows requested ahead too, which is how the first
+    // version of this loop paid a full memory round trip per row with the "prefetch" in place
     auto rload = [&](int i, float4 (&dst)[NV]) {
+        const float* rp = Pb + (size_t)max(min(i, rend - 1), 0) * ldw;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int c = (t * 64 + lane) * 4;
-            dst[t] = (c < ldw && i < rend) ? *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[t] = *reinterpret_cast<const float4*>(rp + min(c, ldw - 4));
         }
     };
-    rload(rbeg + wave, nx);
-    for (int i = rbeg + wave; i < rend; i += 4) {
-        float4 pr[NV];
-        float dot = 0.f;
-#pragma unroll
-        for (int t = 0; t < NV; ++t) pr[t] = nx[t];
-        rload(i + 4, nx);
+    // ... masked where the row is used, by a multiplication: a select would let the compiler put the load back under the predicate
+    auto rmask = [&](int i, const float4 (&src)[NV], float4 (&dst)[NV]) {
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
-            const int c = (t * 64 + lane) * 4;
-            if (c < ldw) {
-                const float4 vv = *reinterpret_cast<const float4*>(sv + c);
+            const float mk = ((t * 64 + lane) * 4 < ldw && i < rend) ? 1.f : 0.f;
+            dst[t] = make_float4(src[t].x * mk, src[t].y * mk, src[t].z * mk, src[t].w * mk);
+        }
+    };
+    // the slots are requested in slot order here too (pinned): the wait at the loop's top is the stricter of what this block and
+    // the loop's end leave outstanding, and interleaved requests would make it "everything"
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        rload(rbeg + wave + 4 * q, nx[q]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int i0 = rbeg + wave; i0 < rend; i0 += 4 * PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            // no early exit: rows past the end run masked (all zeros: they add nothing, and their u is not stored) — a branch
+            // here makes the row slots loop-carried through copies, and copies of registers a load is still writing are waits
+            const int i = i0 + 4 * q;
+            float4 pr[NV];
+            float dot = 0.f;
+            rmask(i, nx[q], pr);
+            __builtin_amdgcn_sched_barrier(0);      // the refill is issued after the slot was read: same registers, no copies (and no wait for them) at the loop's end
+            rload(i + 4 * PF, nx[q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const float4 vv = *reinterpret_cast<const float4*>(sv + (t * 64 + lane) * 4);
                 dot += (pr[t].x * vv.x + pr[t].y * vv.y) + (pr[t].z * vv.z + pr[t].w * vv.w);
             }
-        }
-        dot = wave_sum(dot);
-        const float ri = (i == m) ? (float)(m + 1) : 1.0f;
-        const float ui = ri / (dot + SINK_EPS);
-        if (lane == 0) w.u[(size_t)b * (m_max + 1) + i] = ui;
+            dot = wave_sum(dot);
+            const float ri = (i == m) ? (float)(m + 1) : 1.0f;
+            const float ui = ri / (dot + SINK_EPS);
+            // u_i is kept by lane (row number within the wave) and stored after the loop: with a store outstanding beside the
+            // loads the compiler has to wait with vmcnt(0) (loads and stores return out of order with respect to each other on
+            // gfx9), which would put a full round trip back on every row
+            if (lane == ((i - rbeg) >> 2)) ukeep = ui;      // (rows past the end land in lanes whose store is masked)
 #pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            cacc[t].x += pr[t].x * ui;
-            cacc[t].y += pr[t].y * ui;
-            cacc[t].z += pr[t].z * ui;
-            cacc[t].w += pr[t].w * ui;
+            for (int t = 0; t < NV; ++t) {
+                cacc[t].x += pr[t].x * ui;
+                cacc[t].y += pr[t].y * ui;
+                cacc[t].z += pr[t].z * ui;
+                cacc[t].w += pr[t].w * ui;
+            }
         }
     }
-    float* part = w.part + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
+    {
+        const int i = rbeg + wave + 4 * lane;      // at most ceil(4352 / 32 / 4) = 34 rows per wave
+        if (i < rend) w.u[(size_t)b * (m_max + 1) + i] = ukeep;
+    }
+    float* part = w.part + ((size_t)b * NBLK * 4 + blk * 4 + wave) * ldw;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const int c = (t * 64 + lane) * 4;
@@ -173,9 +226,13 @@ __global__ __launch_bounds__(256) void sink_colreduce_kernel(const int* __restri
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= w.ldw) return;
     const float* part = w.part + (size_t)b * NBLK * 4 * w.ldw + j;
+    // all partials requested before the first is added (the sum itself stays in partial order: it fixes the bits)
+    float pv[NBLK * 4];
+#pragma unroll
+    for (int k = 0; k < NBLK * 4; ++k) pv[k] = part[(size_t)k * w.ldw];
     float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < NBLK * 4; ++k) s += part[(size_t)k * w.ldw];
+#pragma unroll
+    for (int k = 0; k < NBLK * 4; ++k) s += pv[k];
     const float cj = (j == n) ? (float)(n + 1) : 1.0f;
     w.v[(size_t)b * w.ldw + j] = (j <= n) ? cj / (s + SINK_EPS) : 0.f;
 }
@@ -257,22 +314,43 @@ __global__ __launch_bounds__(256) void sink_final_kernel(const int* __restrict__
     }
 }
 
+// column max / argmax over the NBLK * 4 partials of sink_final_kernel.  (value descending, row index ascending) is a total order,
+// so the partials may be combined in any grouping: 32 columns per workgroup, eight threads per column with 16 partials each
+// (all 16 loads in flight), then a reduction through LDS — the one-thread-per-column loop was a chain of 128 dependent round
+// trips, 43 us whatever the batch.
 __global__ __launch_bounds__(256) void sink_colmax_kernel(const int* __restrict__ n_lens, SinkWs w, int n_max) {
+    __shared__ float sval[8][32];
+    __shared__ int sidx[8][32];
     const int b = blockIdx.y;
     const int n = n_lens ? n_lens[b] : n_max;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const float* part = w.part + (size_t)b * NBLK * 4 * w.ldw + j;
-    const int* parti = w.parti + (size_t)b * NBLK * 4 * w.ldw + j;
+    const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jj;
     float best = -INFINITY;
     int bidx = 0x7fffffff;
-    for (int k = 0; k < NBLK * 4; ++k) {
-        const float v = part[(size_t)k * w.ldw];
-        const int i = parti[(size_t)k * w.ldw];
-        if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+    if (j < n) {
+        const float* part = w.part + ((size_t)b * NBLK * 4 + g * (NBLK / 2)) * w.ldw + j;
+        const int* parti = w.parti + ((size_t)b * NBLK * 4 + g * (NBLK / 2)) * w.ldw + j;
+        float v[NBLK / 2];
+        int i[NBLK / 2];
+#pragma unroll
+        for (int k = 0; k < NBLK / 2; ++k) { v[k] = part[(size_t)k * w.ldw]; i[k] = parti[(size_t)k * w.ldw]; }
+#pragma unroll
+        for (int k = 0; k < NBLK / 2; ++k)
+            if (v[k] > best || (v[k] == best && i[k] < bidx)) { best = v[k]; bidx = i[k]; }
     }
-    w.colval[(size_t)b * n_max + j] = best;
-    w.colidx[(size_t)b * n_max + j] = bidx;
+    sval[g][jj] = best;
+    sidx[g][jj] = bidx;
+    __syncthreads();
+    if (g == 0 && j < n) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const float v = sval[q][jj];
+            const int i = sidx[q][jj];
+            if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+        }
+        w.colval[(size_t)b * n_max + j] = best;
+        w.colidx[(size_t)b * n_max + j] = bidx;
+    }
 }
 
 // ---- mutual check + threshold (compute_matches) ------------------------------------------------------
@@ -380,13 +458,13 @@ template <int NV>
 int run_sinkhorn(const float* dist, int ldd, const int* m_lens, const int* n_lens, const float* bin, int iters,
                  float thr, float* p_out, int ldp, long long* matches0, long long* matches1, float* ms0, float* ms1,
                  int batch, int m_max, int n_max, SinkWs w, hipStream_t st, bool dual) {
-    const size_t shm = (size_t)w.ldw * 4;
+    const size_t shm = (size_t)w.ldw * 4, shm_it = (size_t)NV * 256 * 4;      // the iteration kernel pads v with zeros to NV * 256
     dim3 grow(cdiv(m_max + 1, 4), batch), giter(NBLK, batch), gcol(cdiv(w.ldw, 256), batch);
     hipLaunchKernelGGL(sink_init_kernel, grow, dim3(256), 0, st, dist, ldd, (long long)m_max * ldd, m_lens, n_lens, bin,
                        w, m_max, n_max, dual ? 1 : 0);
     if (!dual) {
         for (int it = 0; it < iters; ++it) {
-            hipLaunchKernelGGL(sink_iter_kernel<NV>, giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max);
+            hipLaunchKernelGGL((sink_iter_kernel<NV, 1>), giter, dim3(256), shm_it, st, m_lens, n_lens, w, m_max, n_max);
             hipLaunchKernelGGL(sink_colreduce_kernel, gcol, dim3(256), 0, st, n_lens, w, n_max);
         }
         hipLaunchKernelGGL((sink_final_kernel<NV, 0>), giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
@@ -395,7 +473,7 @@ int run_sinkhorn(const float* dist, int ldd, const int* m_lens, const int* n_len
         hipLaunchKernelGGL(dual_colreduce_kernel, gcol, dim3(256), 0, st, w);
         hipLaunchKernelGGL((sink_final_kernel<NV, 1>), giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
     }
-    hipLaunchKernelGGL(sink_colmax_kernel, dim3(cdiv(n_max, 256), batch), dim3(256), 0, st, n_lens, w, n_max);
+    hipLaunchKernelGGL(sink_colmax_kernel, dim3(cdiv(n_max, 32), batch), dim3(256), 0, st, n_lens, w, n_max);
     hipLaunchKernelGGL(sink_mutual_kernel, dim3(cdiv(m_max > n_max ? m_max : n_max, 256), batch), dim3(256), 0, st, m_lens, n_lens, w,
                        m_max, n_max, thr, matches0, matches1, ms0, ms1);
     return pram_launch_status(dual ? "pram_dual_softmax_match_f32" : "pram_sinkhorn_match_f32");
