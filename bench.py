@@ -555,6 +555,10 @@ def main():
     from pram_amd import _lib as _plib
     chunk_keys = args.attn_chunk_keys if args.attn_chunk_keys is not None else (512 if args.latency else 0)
     chunk_keys = int(_plib.load().pram_attention_x3_set_chunk_keys(int(chunk_keys)))      # 0 = query; process-wide, before the first launch
+    # workgroups a split attention launch aims at: the library's 256 (one per CU); 512 in latency mode (four key groups for a
+    # one-frame launch: 4.19 -> 4.13 ms per query); PRAM_BENCH_SPLIT_TARGET overrides (profiling).  Never changes a result bit.
+    split_target = int(os.environ.get("PRAM_BENCH_SPLIT_TARGET", "512" if args.latency else "-1"))
+    _plib.load().pram_attention_x3_set_split_target(split_target)
     if ops.attention_precision != ops.gemm_precision:
         raise SystemExit(f"bench.py: PRAM_GEMM_PRECISION={ops.gemm_precision} and PRAM_ATTENTION_PRECISION={ops.attention_precision} "
                          f"differ — the line reports ONE arithmetic (use --precision / PRAM_PRECISION)")
@@ -660,6 +664,7 @@ def main():
             saved_ck = L.pram_attention_x3_set_chunk_keys(0)
             if chunk is not None:
                 L.pram_attention_x3_set_chunk_keys(int(chunk))
+                L.pram_attention_x3_set_split_target(512)          # as --latency
             try:
                 j = Job(dev, 0, 1, 0, Bq, **cfg)
                 t, _ = j.timed(steps_, warm_, sync_all)
@@ -673,6 +678,7 @@ def main():
             finally:
                 L.pram_attention_x3_set_p_split(saved_p)
                 L.pram_attention_x3_set_chunk_keys(saved_ck)
+                L.pram_attention_x3_set_split_target(split_target)
             torch.cuda.empty_cache()
 
         alt_run("attention_p_one_fp16", "same step with the soft-max probabilities entering P.V as ONE fp16 (pram_attention_x3_set_p_split(0): two MFMAs per "

@@ -85,30 +85,20 @@ struct NoXform {
     __device__ __forceinline__ void operator()(float4&, int, int) const {}
 };
 
-// DEPTH = chunks of global loads in flight (register sets).  2 is what a full grid wants (more only costs registers: the loop
-// is bandwidth- and power-bound there); 4 is for launches that do not fill the chip — one query frame, 2048 rows — where a
-// chunk is one dependent round trip (0.66 us per chunk with two in flight, measured; the 12 MFMAs of a 64 x 128 tile take 0.2).
-// The contraction order does not depend on it.
-template <int MI, int WN, int DEPTH, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
-__device__ __forceinline__ void mainloop_d(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
-                                           float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf);
-
 template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
 __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
-                                         float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf) {
-    mainloop_d<MI, WN, 2>(s, adv, la, oka, lb, okb, nk, a_scale, acc, amax, axf);
-}
+                                         float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf);
 
 template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk>
 __device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
                                          float a_scale, f32x16 (&acc)[MI][2], float& amax) {
     NoXform none;
-    mainloop_d<MI, WN, 2>(s, adv, la, oka, lb, okb, nk, a_scale, acc, amax, none);
+    mainloop<MI, WN>(s, adv, la, oka, lb, okb, nk, a_scale, acc, amax, none);
 }
 
-template <int MI, int WN, int DEPTH, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
-__device__ __forceinline__ void mainloop_d(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
-                                           float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf) {
+template <int MI, int WN, class Adv, class ALoad, class AOk, class BLoad, class BOk, class AXf>
+__device__ __forceinline__ void mainloop(Smem<MI, WN>& s, Adv& adv, ALoad& la, AOk& oka, BLoad& lb, BOk& okb, int nk,
+                                         float a_scale, f32x16 (&acc)[MI][2], float& amax, AXf& axf) {
     using C = Cfg<MI, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -209,26 +199,25 @@ __device__ __forceinline__ void mainloop_d(Smem<MI, WN>& s, Adv& adv, ALoad& la,
     };
 
     if constexpr (C::PA <= 4) {
-        Regs g[DEPTH];
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q)
-            if (q < nk) { adv(q); issue(q, g[q]); }
-        commit(0, g[0]);
+        Regs g0, g1;
+        adv(0);
+        issue(0, g0);
+        if (nk > 1) { adv(1); issue(1, g1); }
+        commit(0, g0);
         __syncthreads();
         // one step: chunk kt (in LDS buffer kt & 1) is multiplied; `fresh` = the set chunk kt came from (free again: receives
-        // chunk kt + DEPTH), `next` = the set holding chunk kt + 1 (goes to LDS after the MFMAs)
+        // chunk kt + 2), `next` = the set holding chunk kt + 1 (goes to LDS after the MFMAs)
         auto step = [&](int kt, Regs& fresh, Regs& next) {
-            if (kt + DEPTH < nk) { adv(kt + DEPTH); issue(kt + DEPTH, fresh); }
+            if (kt + 2 < nk) { adv(kt + 2); issue(kt + 2, fresh); }
             __builtin_amdgcn_sched_barrier(0);   // the loads go out first; nothing of commit() (its waits!) moves above the MFMAs
             compute(kt & 1);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < nk) commit((kt + 1) & 1, next);
             __syncthreads();
         };
-        for (int kt = 0; kt < nk; kt += DEPTH) {
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q)
-                if (kt + q < nk) step(kt + q, g[q], g[(q + 1) % DEPTH]);
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, g0, g1);
+            if (kt + 1 < nk) step(kt + 1, g1, g0);
         }
     } else {
         // 256-row tiles (64-channel outputs): one register set — a second one does not fit beside 8 staging loads per thread

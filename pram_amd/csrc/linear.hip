@@ -446,8 +446,7 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
 // split-fp16 variant (gemm_core_x3.h): wh / wl = the weight matrix * w_scale split into two fp16 planes [n][K] on the
 // host; activations are split while they are staged.  inv = 1 / (ACT_SCALE * w_scale) undoes both scales (exact).
 // LNA: the A operand is the hidden layer of an MLP tail before its LayerNorm + GELU, applied while it is staged (LnGeluXf)
-// DEPTH: chunks of global loads in flight (gemm_core_x3.h); 4 for launches of at most one workgroup per CU
-template <int MI, int WN, bool LNA = false, int DEPTH = 2>
+template <int MI, int WN, bool LNA = false>
 __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, const _Float16* __restrict__ wh,
                                                                    const _Float16* __restrict__ wl, float inv) {
     using namespace gemmx3;
@@ -498,10 +497,9 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
 #pragma unroll
         for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + 32 * pp, K) : 0.f;
         __syncthreads();
-        mainloop_d<MI, WN, DEPTH>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax, xf);
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax, xf);
     } else {
-        NoXform none;
-        mainloop_d<MI, WN, DEPTH>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax, none);
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax);
     }
     x3_range_flag(p.status, amax);
 #pragma unroll
@@ -777,24 +775,9 @@ void launch_linear_x3_t(LinArgs& p, const _Float16* wh, const _Float16* wl, floa
     using C = gemmx3::Cfg<MI, WN>;
     p.tiles_m = cdiv(p.m, C::BM);
     p.tiles_n = cdiv(p.n, C::BN);
-    // at most one workgroup per CU and a K walk of six chunks or more: the loop is a chain of load round trips -> four in flight
-    static const char* deep_env = getenv("PRAM_X3_DEEP");      // "0": always two (profiling)
-    const bool deep = MI == 1 && p.tiles_m * p.tiles_n <= 256 && p.k0 + p.k1 >= 6 * gemmx3::BK && !(deep_env && deep_env[0] == '0');
     if constexpr (WN == 2) {      // the LayerNorm + GELU operand transform exists for outputs wider than 64 columns (pram_linear_x3_lngelu_f32 checks)
         if (p.ln_ssq) {
-            if constexpr (MI == 1) {
-                if (deep) {
-                    hipLaunchKernelGGL((linear_x3_kernel<MI, WN, true, 4>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
-                    return;
-                }
-            }
             hipLaunchKernelGGL((linear_x3_kernel<MI, WN, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
-            return;
-        }
-    }
-    if constexpr (MI == 1) {
-        if (deep) {
-            hipLaunchKernelGGL((linear_x3_kernel<MI, WN, false, 4>), dim3(p.tiles_m * p.tiles_n, 1), dim3(gemmx3::NT), 0, st, p, wh, wl, inv);
             return;
         }
     }

@@ -66,13 +66,28 @@ class QueryPipeline:
         with ops.guard_scope(guard or self.guard):
             return ops.guarded_call(lambda: self._run(images, ref, stages), images.device)
 
+    def _extract(self, images):
+        return self.sfd2.extract_batched(images, self.cfg, per_image_fallback=True)
+
+    def _recognise(self, ex, images, out):
+        kpts, counts = ex['keypoints'], ex['counts']
+        _, seg = self.sfd2.sample_batched(ex['score_map'], ex['mid_features'], kpts, counts, norm_desc=False)
+        pred = self.segnet({'seg_descriptors': seg, 'keypoints': kpts, 'image': images, 'lens': counts})['prediction']
+        out['prediction'] = pred
+        # recogniser epilogue (Frame.add_segmentations, frame.py:96-121): landmark id = argmax - 1,
+        # background mask at the reference's pre_filtering_th (configs/config_train_7scenes_sfd2.yaml:98)
+        ids, non_bg, n_non_bg, _ = ops.seg_epilogue(pred, counts, self.bg_threshold)
+        out['landmark'], out['non_bg'], out['n_non_bg'] = ids, non_bg, n_non_bg
+
+    def _forks(self, batch: int, ref, stages: str) -> bool:
+        return 'm' in stages and ref is not None and 'r' in stages and batch < self.overlap_below
+
     def _run(self, images, ref, stages):
         B, _, H, W = images.shape
-        ex = self.sfd2.extract_batched(images, self.cfg, per_image_fallback=True)
-        kpts, scores, counts = ex['keypoints'], ex['scores'], ex['counts']
-        out = {'keypoints': kpts, 'scores': scores, 'counts': counts, 'descriptors': ex['descriptors']}
+        ex = self._extract(images)
+        out = {'keypoints': ex['keypoints'], 'scores': ex['scores'], 'counts': ex['counts'], 'descriptors': ex['descriptors']}
         do_match = 'm' in stages and ref is not None
-        forked = do_match and 'r' in stages and B < self.overlap_below
+        forked = self._forks(B, ref, stages)
         if forked:
             main = torch.cuda.current_stream(images.device)
             if self._side is None or self._side.device != images.device:
@@ -81,13 +96,7 @@ class QueryPipeline:
             with torch.cuda.stream(self._side):
                 m = self._match(ex, ref, W, H)
         if 'r' in stages:
-            _, seg = self.sfd2.sample_batched(ex['score_map'], ex['mid_features'], kpts, counts, norm_desc=False)
-            pred = self.segnet({'seg_descriptors': seg, 'keypoints': kpts, 'image': images, 'lens': counts})['prediction']
-            out['prediction'] = pred
-            # recogniser epilogue (Frame.add_segmentations, frame.py:96-121): landmark id = argmax - 1,
-            # background mask at the reference's pre_filtering_th (configs/config_train_7scenes_sfd2.yaml:98)
-            ids, non_bg, n_non_bg, _ = ops.seg_epilogue(pred, counts, self.bg_threshold)
-            out['landmark'], out['non_bg'], out['n_non_bg'] = ids, non_bg, n_non_bg
+            self._recognise(ex, images, out)
         if do_match:
             if forked:
                 main.wait_stream(self._side)
@@ -161,7 +170,7 @@ class GraphedPipeline:
     re-issue for callers that keep several steps in flight and check ``ops.x3_range_exceeded()`` themselves."""
 
     def __init__(self, pipe: QueryPipeline, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm",
-                 warmup: int = 2, record: bool = False):
+                 warmup: int = 2, record: bool = False, split: Optional[bool] = None):
         self.pipe, self.stages = pipe, stages
         self.images = images.clone()
         self.ref = None if ref is None else {k: v.clone() for k, v in ref.items()}
@@ -169,6 +178,12 @@ class GraphedPipeline:
         self.record = None
         self._ws = {}                 # this graph's private scratch (ops.workspace_scope): never shared, never regrown by others
         self._side = torch.cuda.Stream(device=images.device) if pipe.overlap_below > images.shape[0] else None
+        # A step that forks (recognise || match, small batches) is captured as FOUR graphs — extract | match | recognise | record —
+        # replayed on two streams: the runtime issues the branches of ONE hipGraph one after the other (measured: a two-branch graph
+        # of 2 x 150 kernels replays in 838 us, the same 300 in one chain in 499 us; in the traced step the recogniser's first kernel
+        # starts when the matcher is almost through), and it is the overlap of the two that a one-query step lives on.
+        forks = pipe._forks(images.shape[0], ref, stages)
+        self.split = forks if split is None else (bool(split) and forks)
         side = torch.cuda.Stream(device=images.device)
         side.wait_stream(torch.cuda.current_stream(images.device))
         with ops.workspace_scope(self._ws):
@@ -177,9 +192,49 @@ class GraphedPipeline:
                     self._run_eager()
             torch.cuda.current_stream(images.device).wait_stream(side)
             torch.cuda.synchronize(images.device)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._run_eager()
+            if not self.split:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = self._run_eager()
+            else:
+                self._capture_split()
+
+    def _capture_split(self):
+        pipe, images = self.pipe, self.images
+        _, _, H, W = images.shape
+        self.g_e, self.g_m, self.g_r, self.g_f = (torch.cuda.CUDAGraph() for _ in range(4))
+        # the matcher is captured on the stream it will be replayed on: scratch memory is keyed by stream (ops._workspace), and
+        # the two branches must not share any; each graph allocates from its own pool (a pool shared by graphs that run at the
+        # same time would hand the temporaries of one to the other)
+        cap = torch.cuda.Stream(device=images.device)
+        with ops.guard_scope("deferred"):
+            with torch.cuda.graph(self.g_e, stream=cap):
+                ex = pipe._extract(images)
+            out = {'keypoints': ex['keypoints'], 'scores': ex['scores'], 'counts': ex['counts'], 'descriptors': ex['descriptors']}
+            with torch.cuda.graph(self.g_m, stream=self._side):
+                m = pipe._match(ex, self.ref, W, H)
+            with torch.cuda.graph(self.g_r, stream=cap):
+                pipe._recognise(ex, images, out)
+            out['matches0'], out['matching_scores0'] = m['matches0'], m['matching_scores0']
+            if self.with_record:
+                with torch.cuda.graph(self.g_f, stream=cap):
+                    self.record = QueryPipeline.pack_record(out)
+        self._ex = ex                 # keeps the extractor's tensors (graph-pool memory the other graphs read) alive
+        self.out = out
+
+    def _replay(self):
+        if not self.split:
+            self.graph.replay()
+            return
+        main = torch.cuda.current_stream(self.images.device)
+        self.g_e.replay()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self.g_m.replay()
+        self.g_r.replay()
+        main.wait_stream(self._side)
+        if self.with_record:
+            self.g_f.replay()
 
     def _run_eager(self):
         # the forked branch runs on a side stream owned by THIS graph (the pipeline's own side stream keeps serving eager runs)
@@ -195,7 +250,7 @@ class GraphedPipeline:
     def replay(self) -> Dict[str, torch.Tensor]:
         """Re-issue the captured step on the current stream with the inputs already in the captured buffers; no synchronisation,
         no range-guard check."""
-        self.graph.replay()
+        self._replay()
         return self.out
 
     @torch.no_grad()
@@ -212,7 +267,7 @@ class GraphedPipeline:
         if ref is not None:
             for k, v in ref.items():
                 self.ref[k].copy_(v)
-        self.graph.replay()
+        self._replay()
         guard = self.pipe.guard
         if guard != "deferred" and "x3" in (ops.gemm_precision, ops.attention_precision) and ops.x3_range_exceeded(images.device):
             if guard == "raise":

@@ -96,8 +96,10 @@ def test_batches_in_flight_on_separate_streams_equal_serial(dev):
             assert torch.equal(a, b)
 
 
-def test_graphed_pipeline_equals_eager(dev):
-    """the whole step captured as a hipGraph (no host synchronisation inside) and replayed on new inputs == eager run"""
+@pytest.mark.parametrize("split", [True, False])
+def test_graphed_pipeline_equals_eager(dev, split):
+    """the whole step captured (no host synchronisation inside) and replayed on new inputs == eager run: as four graphs on two
+    streams (extract | match || recognise | record: what a forking step gets by default) and as one hipGraph"""
     from pram_amd.pipeline import GraphedPipeline, QueryPipeline
     sfd2, seg, gml = _models(dev)
     pipe = QueryPipeline(sfd2, seg, gml, max_keypoints=192, min_keypoints=8)
@@ -106,10 +108,12 @@ def test_graphed_pipeline_equals_eager(dev):
     ex = sfd2.extract_batched(imgs[0], pipe.cfg)
     ref = {"descriptors": ex["descriptors"].flip(1).contiguous(), "keypoints": ex["keypoints"].flip(1).contiguous(),
            "scores": ex["scores"].flip(1).contiguous()}
-    g = GraphedPipeline(pipe, imgs[0], ref)
+    g = GraphedPipeline(pipe, imgs[0], ref, split=split, record=True)
+    assert g.split == split
     for img in imgs[1:] + imgs[:1]:
         want = QueryPipeline.pack_record(pipe.run(img, ref)).clone()
         got = QueryPipeline.pack_record(g.run(img, ref))
         assert torch.equal(got, want)
+        assert torch.equal(g.record, want)          # the captured record
     with pytest.raises(ValueError):
         g.run(imgs[0][:1], ref)
