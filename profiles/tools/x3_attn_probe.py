@@ -37,4 +37,5 @@ for B, N in ((16, 2048), (32, 2048), (8, 4096), (1, 2048), (2, 2048)):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     fl = 4.0 * B * 4 * N * N * 64
-    print(f"mode={os.environ.get('PRAM_ATTN_MODE', 'auto')} ablate={os.environ.get('PRAM_ATTN_ABLATE', '0')} B={B:3d} N={N}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic ({fl * 2.5 / us / 1e6:7.1f} executed)")
+    per_product = ops._lib.load().pram_attention_x3_mfma_per_tile(N) / 16.0      # 3 (two-part probabilities, the default) or 2.5
+    print(f"mode={os.environ.get('PRAM_ATTN_MODE', 'auto')} ablate={os.environ.get('PRAM_ATTN_ABLATE', '0')} B={B:3d} N={N}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s algorithmic ({fl * per_product / us / 1e6:7.1f} executed, {per_product:g} MFMAs per product)")
