@@ -410,8 +410,8 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
         const int rc = min(row0 + arow + 16 * pp, mlast);
         const int kc = min(kt * BK + akq * 4, K - 4);
         const bool second = (kt * BK >= p.k0) && p.k1 > 0;            // wave-uniform: k0 % 64 == 0
-        if (second ? p.a1_f16 : p.a0_f16) {                            // fp16 segment (wave-uniform): four halves, widened losslessly
-            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+        if (WN == 2 && (second ? p.a1_f16 : p.a0_f16)) {               // fp16 segment (wave-uniform): four halves, widened losslessly.  Wide outputs only:
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));     // in the 256-row tile (WN = 1) the second path costs 43 spilled registers
             const _Float16* src = second ? (reinterpret_cast<const _Float16*>(p.a1) + (size_t)rc * p.lda1 + (kc - p.k0))
                                          : (reinterpret_cast<const _Float16*>(p.a0) + (size_t)rc * p.lda0 + kc);
             const half4v hv = *reinterpret_cast<const half4v*>(src);
@@ -1031,7 +1031,7 @@ extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const floa
     hipStream_t st = (hipStream_t)stream;
     const _Float16* w = (const _Float16*)w16;
     if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
-    else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
+    else launch_linear_f16_t<1, 1>(p, w, st);      // 128-row tiles for narrow outputs: the 256-row instantiation spills (43 registers) on this path
     return pram_launch_status("pram_linear_f16_f32");
 }
 
@@ -1053,7 +1053,7 @@ extern "C" int pram_linear_f16_h16(const float* a0, int lda0, int k0, const floa
     hipStream_t st = (hipStream_t)stream;
     const _Float16* w = (const _Float16*)w16;
     if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
-    else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
+    else launch_linear_f16_t<1, 1>(p, w, st);      // 128-row tiles for narrow outputs: the 256-row instantiation spills (43 registers) on this path
     return pram_launch_status("pram_linear_f16_h16");
 }
 
@@ -1197,10 +1197,11 @@ static int linear_f16_impl(const char* who, const float* a0, int lda0, int k0, i
     }
     int mi, wn;
     gemm::choose_tile(m, n, &mi, &wn);
+    PRAM_REQUIRE(wn == 2 || !(a0_f16 || a1_f16), "%s: fp16 input segments need an output wider than 64 columns (n = %d)", who, n);
     hipStream_t st = (hipStream_t)stream;
     const _Float16* w = (const _Float16*)w16;
     if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
-    else         { if (mi == 2) launch_linear_f16_t<2, 1>(p, w, st); else launch_linear_f16_t<1, 1>(p, w, st); }
+    else launch_linear_f16_t<1, 1>(p, w, st);      // 128-row tiles for narrow outputs: the 256-row instantiation spills (43 registers) on this path
     return pram_launch_status(who);
 }
 

@@ -19,7 +19,10 @@ def planes(t):
     return hi.contiguous(), (s - hi.float()).half().contiguous()
 
 
-for B, N in ((16, 2048), (32, 2048), (8, 4096), (1, 2048), (2, 2048)):
+SHAPES = ((16, 2048), (32, 2048), (8, 4096), (1, 2048), (2, 2048))
+if os.environ.get("PRAM_PROBE_SHAPES"):      # e.g. "4x2048,8x2048,12x2048": a batch sweep
+    SHAPES = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["PRAM_PROBE_SHAPES"].split(","))
+for B, N in SHAPES:
     q = torch.randn(B * N, 256, device=dev)
     k = torch.randn(B * N, 256, device=dev)
     v = torch.randn(B * N, 256, device=dev)

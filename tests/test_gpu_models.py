@@ -141,8 +141,9 @@ def test_segnetvit_ragged_batch(dev):
 
 def test_c5_fp16_attention_path_tolerance(dev):
     """BASELINE config C5 ('fp16 MFMA path', 4096 keypoints): fp16-operand attention inside the otherwise-fp32 models.
-    Own, looser, documented tolerance: logits within 3e-2 of the fp32 oracle, argmax agreement >= 99 %; matcher index
-    agreement >= 98 % (indices are NOT promised bit-exact on this path)."""
+    Own, looser, documented tolerance — the bars are 2 x what the path measures (printed below; round 3: attention only 1.55e-2 /
+    0.9983 / 1.0, attention + GEMMs 3.1-3.4e-2 / 0.9973-0.9978 / 1.0, the higher figures with PRAM_F16_ACT=1): indices are NOT
+    promised bit-exact on this path."""
     from pram_amd import ops
     desc, kp = _tokens(1, 4096)
     ref = R.segnetvit_forward(H.segnet_sd(161), desc, kp, (1, 3, 480, 640))
@@ -161,7 +162,7 @@ def test_c5_fp16_attention_path_tolerance(dev):
     ds = H.maxdiff(rm["matching_scores0"], refm["matching_scores0"])
     print(f"C5 fp16 attention: segnetvit N=4096 nc161 |logit - oracle| {d:.2e}, argmax agreement {agree:.4f}; "
           f"gml 1024x1024 index agreement {magree:.4f}, score diff {ds:.2e}")
-    assert d < 3e-2 and agree >= 0.99 and magree >= 0.98
+    assert d < 3.1e-2 and agree >= 0.9966 and magree >= 0.99
     # full fp16 MFMA path: attention AND token GEMMs with fp16 operands (fp32 accumulate / softmax / LayerNorm)
     ops.attention_precision = ops.gemm_precision = "f16"
     try:
@@ -173,7 +174,7 @@ def test_c5_fp16_attention_path_tolerance(dev):
     agree = (out.argmax(-1).cpu() == ref.argmax(-1)).float().mean().item()
     magree = (rm["matches0"].cpu() == refm["matches0"]).float().mean().item()
     print(f"C5 fp16 attention + GEMM: |logit - oracle| {d:.2e}, argmax agreement {agree:.4f}; gml index agreement {magree:.4f}")
-    assert d < 0.25 and agree >= 0.97 and magree >= 0.95
+    assert d < 6.7e-2 and agree >= 0.994 and magree >= 0.99
 
 
 def _gml(dev):
