@@ -219,7 +219,7 @@ int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, c
  * fp16 MFMAs with fp32 accumulation: three per product for the scores; two per product for P V from 1024 keys on (the
  * probabilities enter as one fp16), three below (pram_attention_x3_mfma_per_tile).  Output fp32.
  * kv_shift as in pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs).
- * Key chunks: from 1024 keys on the keys are reduced in chunks (pram_attention_x3_set_chunk_keys: default 2048 keys), each chunk
+ * Key chunks: from 1024 keys on the keys are reduced in chunks (pram_attention_x3_set_chunk_keys: default 4096 keys, i.e. one chunk for every shipped configuration), each chunk
  * normalised and all chunks folded in chunk order.  One workgroup normally walks all chunks of its 128 query rows and folds them
  * in registers; an under-filled launch (pram_attention_x3_is_split: one or two query frames, the reference's online loop
  * localization/loc_by_rec_online.py:109-133) runs groups of chunks as a second grid dimension, parks them in `workspace`
@@ -231,10 +231,10 @@ int pram_attention_x3_is_split(int batch, int heads, int m_max, int n_max);
  * `workgroups` (default 256 = one per CU; 0 = never; negative restores the default); returns the previous value.  The mode never
  * changes a result bit.  pram_attention_x3_is_split returns the number of groups (1 = fused). */
 int pram_attention_x3_set_split_target(int workgroups);
-/* keys per chunk (a multiple of 128; default 2048 or the environment's PRAM_ATTN_CHUNK_KEYS), process-wide: set it before the first
+/* keys per chunk (a multiple of 128; default 4096 or the environment's PRAM_ATTN_CHUNK_KEYS), process-wide: set it before the first
  * launch — it fixes where EVERY launch folds its partial soft-maxes (results move in their last bits, consistently for all batch
  * sizes).  Smaller chunks let shorter key sets use the split mode; a fused walk pays a spill round trip at every chunk end
- * (+15 % kernel time at 512 keys per chunk for 2048-key sets, ~1 % at 2048 for 4096-key sets).  0 = query; returns the value. */
+ * (+17 % kernel time at 512 keys per chunk for 2048-key sets, +6 % at 2048 for 4096-key sets).  0 = query; returns the value. */
 int pram_attention_x3_set_chunk_keys(int keys);
 int pram_attention_x3_mfma_per_tile(int n_max);
 /* probabilities in P V from 1024 keys on: 1 = two fp16 parts (three MFMAs per product; default), 0 = one fp16 (two MFMAs, ~15 % less

@@ -57,12 +57,13 @@ struct ArgsX {
 // its normalised chunk results in a caller-owned workspace and combine_x3_kernel applies the SAME fold in the SAME order, so the
 // output does not depend on which mode ran, bit for bit: a padded batch element still equals its B = 1 run exactly.
 // Chunk size.  A fused walk folds a running total at every chunk end; the total does not fit in the 256 registers of a wave
-// beside the pipeline's two score tiles, so each chunk end costs a spill round trip: 512-key chunks +15 % kernel time at 2048
-// keys, 2048-key chunks ~1 % at 4096 keys (profiles/r03_x3_attention_chunks.txt).  The default is therefore 2048 keys — the
-// shipped 2048-keypoint configurations run one chunk and pay nothing, 4096 keys run two — and pram_attention_x3_set_chunk_keys
-// lowers it for deployments that want the split mode at 2048 keys (it moves the chunk boundaries of EVERY launch, so results
-// change in their last bits consistently, never between batch sizes).
-constexpr int DEFAULT_CHUNK_TILES = 32;         // 2048 keys (g_chunk_tiles; pram_attention_x3_set_chunk_keys)
+// beside the pipeline's two score tiles, so the chunked kernel spills: with two-part probabilities it is 5 % slower than the
+// unchunked one before it folds anything, +17 % with 512-key chunks at 2048 keys, +6 % with two 2048-key chunks at 4096 keys
+// (profiles/r03_x3_attention_chunks.txt).  The default is therefore 4096 keys — every shipped configuration (2048 and 4096
+// keypoints) runs ONE chunk, the unchunked kernel, and pays nothing — and pram_attention_x3_set_chunk_keys lowers it for
+// deployments that want the split mode for one-frame launches (bench.py --latency: 512; it moves the chunk boundaries of EVERY
+// launch of the process, so results change in their last bits consistently, never between batch sizes).
+constexpr int DEFAULT_CHUNK_TILES = 64;         // 4096 keys (g_chunk_tiles; pram_attention_x3_set_chunk_keys)
 constexpr int SPLIT_TARGET = 256;               // split launches aim at this many workgroups: one per CU (g_split_target)
 
 __device__ __forceinline__ void fold_weights(float lt, float lc, float* at, float* ac, float* lnew) {
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     half8 ph[2][2], pl[2][2];
     // Chunk bookkeeping.  MODE 1 (fused): a running total (o_tot, l_tot2) is folded at every chunk end by the left fold
     // combine_x3_kernel applies; it does not fit beside the two score tiles of the software pipeline (256 registers at two waves
-    // per SIMD), the compiler spills and reloads it around the chunk end: ~1 % at 2048-key chunks, 15 % at 512.  MODE 2 (split):
+    // per SIMD), the compiler spills and reloads it around the chunk end: +6 % for two 2048-key chunks, +17 % at 512.  MODE 2 (split):
     // every chunk of the workgroup's key group is PARKED in the workspace, [chunk][row][head * 64 + d] / [chunk][batch][head][row].
     // MODE 0: one chunk, nothing to fold.
     // (A fused variant that parked its chunks like MODE 2 and folded them after the last tile — no spill — was dropped: compiled
@@ -996,7 +997,7 @@ static size_t x3_ws_bytes(int batch, int heads, int m_max, int n_max) {
     return (size_t)nchunks * batch * m_max * (heads * D + heads) * sizeof(float);
 }
 
-/* Keys per chunk of pram_attention_x3_f32 (a multiple of 128; default 2048, or PRAM_ATTN_CHUNK_KEYS): process-wide, to be set
+/* Keys per chunk of pram_attention_x3_f32 (a multiple of 128; default 4096, or PRAM_ATTN_CHUNK_KEYS): process-wide, to be set
    before the first launch — it fixes where every launch folds its partial soft-maxes.  0 keeps the current value; returns it. */
 extern "C" int pram_attention_x3_set_chunk_keys(int keys) {
     if (keys >= 128 && keys % 128 == 0) g_chunk_tiles = keys / BKV;

@@ -281,10 +281,10 @@ def test_x3_attention_many_workgroups_every_mode(dev, chunk_keys, p_split):
         L.pram_attention_x3_set_p_split(prev)
 
 
-@pytest.mark.parametrize("ck", [512, 2048])
+@pytest.mark.parametrize("ck", [512, 4096])
 def test_batched_matcher_equals_b1_with_split_attention(dev, chunk_keys, ck):
     """GML on 2048-keypoint sets: a batch of 5 pairs (fused attention launches) gives every pair exactly the bits of its own B = 1
-    call (split attention launches with 512-key chunks; one chunk per sequence at the default 2048)."""
+    call (split attention launches with 512-key chunks; one chunk per sequence at the default 4096)."""
     from pram_amd.nets.gml import GML
     chunk_keys(ck)
     net = GML({})

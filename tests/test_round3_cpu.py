@@ -113,13 +113,14 @@ def test_new_entry_points_are_declared_bound_and_exported():
     finally:
         L.pram_attention_x3_set_p_split(prev)
     assert L.pram_linear_x3_ssq_parts(1000, 512, 512) == 8 and L.pram_linear_x3_ssq_parts(1, 1024, 256) == 16
-    # the key-chunk geometry (no GPU needed): one chunk per 2048 keys by default -> no workspace, no split at 2048 keys
-    assert L.pram_attention_x3_set_chunk_keys(0) == 2048
+    # the key-chunk geometry (no GPU needed): one chunk per 4096 keys by default -> no workspace, no split at 2048 or 4096 keys
+    assert L.pram_attention_x3_set_chunk_keys(0) == 4096
+    assert L.pram_attention_x3_workspace_bytes(8, 4, 4096, 4096) == 0 and L.pram_attention_x3_is_split(1, 4, 4096, 4096) == 1
     assert L.pram_attention_x3_workspace_bytes(1, 4, 2048, 2048) == 0 and L.pram_attention_x3_is_split(1, 4, 2048, 2048) == 1
-    assert L.pram_attention_x3_workspace_bytes(1, 4, 4096, 4096) > 0 and L.pram_attention_x3_is_split(1, 4, 4096, 4096) == 2
+    assert L.pram_attention_x3_workspace_bytes(1, 4, 2048, 8192) > 0 and L.pram_attention_x3_is_split(1, 4, 2048, 8192) == 2
     assert L.pram_attention_x3_set_chunk_keys(512) == 512
     try:
         assert L.pram_attention_x3_is_split(1, 4, 2048, 2048) == 4 and L.pram_attention_x3_is_split(2, 4, 2048, 2048) == 2
         assert L.pram_attention_x3_is_split(16, 4, 2048, 2048) == 1 and L.pram_attention_x3_is_split(1, 4, 512, 512) == 1
     finally:
-        L.pram_attention_x3_set_chunk_keys(2048)
+        L.pram_attention_x3_set_chunk_keys(4096)
