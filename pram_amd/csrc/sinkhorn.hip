@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256) void sink_init_kernel(const float* __restrict_
 // sit in exec branches and the compiler waits with vmcnt(0) at the joins; (b) a store inside the loop (u_i) beside outstanding
 // loads forces vmcnt(0) — loads and stores return out of order with respect to each other on gfx9; (c) a loop the compiler takes
 // for divergent carries the row slots through copies, and a copy of a register a load is still writing is a wait; (d) v was
-// copied to LDS by a scalar loop: nine dependent round trips.  More rows ahead (PF = 2, 4) or one wave per workgroup on 128 CUs
-// measured the same or worse — what is left is the chain itself (six ds_bpermute steps and a division per row).  The rows of a
-// wave are reduced in the same order whatever PF is: the partial sums do not depend on it.
+// copied to LDS by a scalar loop: nine dependent round trips.  More rows ahead (PF = 2, 4), one wave per workgroup on 128 CUs, and two
+// rows reduced side by side (their six-step wave reductions and divisions interleaved) all measured the same or worse: 128 waves
+// pull 17 MB at ~10 GB/s each whatever they keep in flight, and the 128 row groups are fixed by the bits (the order in which
+// rows are added into a column partial).  The rows of a wave are reduced in the same order whatever PF is.
 template <int NV, int PF>
 __global__ __launch_bounds__(256) void sink_iter_kernel(const int* __restrict__ m_lens, const int* __restrict__ n_lens,
                                                         SinkWs w, int m_max, int n_max) {
