@@ -338,11 +338,17 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
 // the kernel above; the soft-max is written with packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32).
 // HI: single-product mode (BASELINE C5's fp16 path): only the hi planes exist (q / k / v rounded to fp16, scale p.in_scale = 1),
 // one MFMA per product; half the LDS, so the co-residency is bounded by registers only.
-// MODE 0: one online soft-max over all keys (short key sets: PSPLIT, always fused); 1: fused, key chunks parked in the workspace
-// and folded at the end; 2: split — blockIdx.y = key chunk, the chunk result goes to the workspace, combine_x3_kernel folds;
-// 3: fused without a workspace (running fold in registers / scratch: slower) — see "Key chunks" above.
-template <bool PSPLIT, bool HI = false, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
+// MODE 0: one online soft-max over all keys (one key chunk: every launch at the default chunk size); 1: fused, key chunks folded
+// into a running total in registers / scratch; 2: split — blockIdx.y = group of key chunks, the chunk results go to the workspace,
+// combine_x3_kernel folds — see "Key chunks" above.
+// NWV: waves per workgroup.  Four (128 query rows, two workgroups per CU) everywhere but on full grids of MODE 0, where eight
+// (256 rows, one workgroup per CU: the same 64 KB of LDS, the same registers per wave) stage every K / V tile once per 256 query
+// rows instead of once per 128 — the staging is what the tile loop pays for beside its MFMAs (profiles/r02_x3_attention_ablation.txt).
+template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW>
+__global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe_kernel(ArgsX p) {
+    constexpr int BQV = QW * NWV;            // query rows of the workgroup
+    constexpr int SROWS = NWV * 8;           // K rows / V^T rows one staging pass of the workgroup covers (8 threads per row)
+    constexpr int PPN = BKV / SROWS;         // staging passes per tile
     static_assert(!(HI && PSPLIT), "the single-product mode carries one plane of everything");
     __shared__ typename SmemSel<HI>::type s;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -355,11 +361,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
     const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
     const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
-    if (qt * BQ >= qlen) return;
+    if (qt * BQV >= qlen) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qt * BQ + wave * QW;
+    const int q0 = qt * BQV + wave * QW;
     const bool wave_active = q0 < qlen;
     const int qrow = q0 + r;
     const bool q_ok = qrow < qlen;
@@ -393,27 +399,27 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     }
 
     const int lrow = tid >> 3, lseg = tid & 7;
-    half8 krh[2], krl[2], vrh[2], vrl[2];
+    half8 krh[PPN], krl[PPN], vrh[PPN], vrl[PPN];
     auto gload_k = [&](int kt) {
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const size_t kc = (size_t)min(kt * BKV + lrow + 32 * pp, klen - 1);
+        for (int pp = 0; pp < PPN; ++pp) {
+            const size_t kc = (size_t)min(kt * BKV + lrow + SROWS * pp, klen - 1);
             krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
             if constexpr (!HI) krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
         }
     };
     auto gload_v = [&](int kt) {
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const size_t vo = voff + (size_t)(lrow + 32 * pp) * p.tv + kt * BKV + lseg * 8;
+        for (int pp = 0; pp < PPN; ++pp) {
+            const size_t vo = voff + (size_t)(lrow + SROWS * pp) * p.tv + kt * BKV + lseg * 8;
             vrh[pp] = *reinterpret_cast<const half8*>(p.vh + vo);
             if constexpr (!HI) vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
         }
     };
     auto lstore_k = [&](int buf) {
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int row = lrow + 32 * pp;
+        for (int pp = 0; pp < PPN; ++pp) {
+            const int row = lrow + SROWS * pp;
             const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
             *reinterpret_cast<half8*>(&s.kh[buf][off]) = krh[pp];
             if constexpr (!HI) *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
@@ -421,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     };
     auto lstore_v = [&](int buf) {
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int row = lrow + 32 * pp;
+        for (int pp = 0; pp < PPN; ++pp) {
+            const int row = lrow + SROWS * pp;
             const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);
             *reinterpret_cast<half8*>(&s.vth[buf][off]) = vrh[pp];
             if constexpr (!HI) *reinterpret_cast<half8*>(&s.vtl[buf][off]) = vrl[pp];
@@ -490,13 +496,13 @@ __global__ __launch_bounds__(256, 2) void attention_x3_pipe_kernel(ArgsX p) {
     auto part_ptr = [&](int c) -> float* {
         int z = 0;
         asm volatile("" : "+v"(z));
-        const size_t row = (size_t)b * p.m_max + min(qt * BQ + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
+        const size_t row = (size_t)b * p.m_max + min(qt * BQV + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
         return p.part_o + ((size_t)c * p.batch * p.m_max + row) * (p.heads * D) + head * D;
     };
     auto part_lse = [&](int c) -> float* {
         int z = 0;
         asm volatile("" : "+v"(z));
-        const size_t li = ((size_t)b * p.heads + head) * p.m_max + min(qt * BQ + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
+        const size_t li = ((size_t)b * p.heads + head) * p.m_max + min(qt * BQV + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
         return p.part_l + (size_t)c * p.batch * p.heads * p.m_max + li;
     };
     // end of a key chunk inside the walk (MODE 1 / 2): normalise it, fold it (1) or park it (2), start afresh
@@ -1091,6 +1097,17 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
         const int fm = force ? atoi(force) : -1;
         const int nchunks = cdiv(n_max, chunk_tiles() * BKV);
         if (fm == 0 || (nchunks < 2 && fm != 1)) {      // one chunk per sequence: the walk is the unchunked kernel's (a fold from (0, -inf) is exact)
+            // a grid that fills the chip with 256-row workgroups runs eight waves per workgroup (NWV): every K / V tile is staged once
+            // per 256 query rows.  PRAM_ATTN_WAVES=4 keeps the 128-row workgroups (profiling); the choice never changes a bit.
+            static const char* wv = getenv("PRAM_ATTN_WAVES");
+            const long units256 = (long)batch * heads * cdiv(m_max, 2 * BQ);
+            if (units256 >= 256 && !(wv && wv[0] == '4')) {
+                p.q_tiles = cdiv(m_max, 2 * BQ);
+                const dim3 grid8(batch * heads * p.q_tiles), blk8(2 * NW * 64);
+                if (psplit) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0, 2 * NW>), grid8, blk8, 0, st, p);
+                else hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 0, 2 * NW>), grid8, blk8, 0, st, p);
+                return pram_launch_status("pram_attention_x3_f32");
+            }
             PRAM_LAUNCH_PIPE(0, grid);
             return pram_launch_status("pram_attention_x3_f32");
         }
