@@ -1144,6 +1144,18 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     return pram_launch_status("pram_attention_x3_f32");
 }
 
+// single-product launches: eight waves per workgroup on grids that fill the chip with 256-row workgroups (as pram_attention_x3_f32)
+static void launch_h16t(ArgsX& p, hipStream_t st) {
+    static const char* wv = getenv("PRAM_ATTN_WAVES");
+    const long units256 = (long)p.batch * p.heads * cdiv(p.m_max, 2 * BQ);
+    if (units256 >= 256 && !(wv && wv[0] == '4')) {
+        p.q_tiles = cdiv(p.m_max, 2 * BQ);
+        hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0, 2 * NW>), dim3(p.batch * p.heads * p.q_tiles), dim3(2 * NW * 64), 0, st, p);
+        return;
+    }
+    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0>), dim3(p.batch * p.heads * p.q_tiles), dim3(256), 0, st, p);
+}
+
 /* Single-product ("fp16 MFMA path", BASELINE C5) flash attention on the pipelined kernel: q / k = fp16 row-major [rows][ld]
    (what pram_linear_f16_h16 writes), vt = the transposed, key-permuted fp16 values of pram_attention_x3_vt called with NULL lo
    planes.  One fp16 MFMA per product, fp32 accumulation and soft-max; the probabilities are rounded to fp16 (scaled by 2^14)
@@ -1158,7 +1170,7 @@ extern "C" int pram_attention_h16t_f32(const void* q16, int ldq, const void* k16
     PRAM_REQUIRE(n_max > 0, "pram_attention_h16t_f32: empty key set");
     ArgsX p{(const _Float16*)q16, nullptr, (const _Float16*)k16, nullptr, (const _Float16*)vt16, nullptr, out, lse2, q_lens, k_lens,
             ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f, 1, 0, 0, nullptr, nullptr};
-    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    launch_h16t(p, (hipStream_t)stream);
     return pram_launch_status("pram_attention_h16t_f32");
 }
 
@@ -1175,6 +1187,6 @@ extern "C" int pram_attention_h16t_h16(const void* q16, int ldq, const void* k16
     ArgsX p{(const _Float16*)q16, nullptr, (const _Float16*)k16, nullptr, (const _Float16*)vt16, nullptr, nullptr, lse2, q_lens, k_lens,
             ldq, ldk, cdiv(n_max, 64) * 64, 0, batch, heads, m_max, n_max, scale * LOG2E, cdiv(m_max, BQ), kv_shift, 1.0f, 1, 0, 0, nullptr, nullptr,
             (_Float16*)out16, ldo16};
-    hipLaunchKernelGGL((attention_x3_pipe_kernel<false, true, 0>), dim3(batch * heads * p.q_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    launch_h16t(p, (hipStream_t)stream);
     return pram_launch_status("pram_attention_h16t_h16");
 }
