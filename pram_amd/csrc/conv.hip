@@ -348,6 +348,185 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
     conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 
+// ---------------------------------------------------------------- 3x3 / stride 1 with the input window resident in LDS
+// conv_x3w_kernel stages (and splits) the A operand once per K chunk, i.e. once per TAP: every input element of a 3x3 layer goes
+// L2 -> registers -> two fp16 parts -> LDS nine times.  Here a workgroup owns 8 x 32 output pixels x 256 channels, and per
+// 32-channel slab of the input its (8 + 2) x (32 + 2) pixel window is staged and split ONCE (zero padding written into the tile);
+// the nine taps read their A fragments from that window at shifted pixel rows.  Only the weights still move per chunk (LDS-DMA).
+// A: 43.5 KB per stage x 2 (the next slab's window is requested at the slab's first tap and written at its last), B: 32 KB x 2.
+// K is walked slab by slab with the taps innermost and every accumulator sees lo.hi, hi.lo, hi.hi per 16-deep step — the order
+// of conv_x3w_kernel: the two kernels agree bit for bit (tests/test_gpu_round3.py::test_conv3x3_halo_equals_chunked).
+namespace halo {
+constexpr int TH = 8, TW = 32, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;      // 340 window pixels
+constexpr int BK = 32, BN = 256, NT = 512, MI = 4, WN = 4;
+constexpr int NL = (HP * 8 + NT - 1) / NT;                                      // float4 loads per thread and slab (6)
+struct alignas(16) Smem {
+    _Float16 ah[2][HP * BK];
+    _Float16 al[2][HP * BK];
+    _Float16 bh[2][BN * BK];
+    _Float16 bl[2][BN * BK];
+};      // 152 576 bytes
+}  // namespace halo
+
+__global__ __launch_bounds__(halo::NT, 1) void conv3x3_x3h_kernel(ConvArgs p, const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
+                                                                  float inv, int tiles_x, int tiles_y) {
+    using namespace halo;
+    using gemmx3::half4;
+    using gemmx3::half8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int tn = id % p.tiles_n;
+    int t = id / p.tiles_n;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, col0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int nlast = p.cout - 1;
+
+    // window staging: element e = tid + NT j is float4 q = e % 8 of window pixel hp = e / 8.  The geometry is recomputed where it is
+    // used (once per slab and element: a dozen integer operations) instead of living in twelve registers across the tap loop.
+    struct Geo { int hp, q; bool valid, inimg; unsigned goff; };
+    auto geo = [&](int j) {
+        Geo g;
+        const int e = tid + NT * j;
+        g.valid = (e >> 3) < HP;
+        g.hp = min(e >> 3, HP - 1);
+        g.q = e & 7;
+        const int hy = g.hp / HWD, hx = g.hp - hy * HWD;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        g.inimg = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+        const int iyc = min(max(iy, 0), p.h - 1), ixc = min(max(ix, 0), p.wd - 1);
+        g.goff = (unsigned)((iyc * p.wd + ixc) * p.cin + g.q * 4);      // a batch element is < 2^32 floats
+        return g;
+    };
+    float amax = 0.f;
+    float4 hv[NL];
+    const float* img = p.in + (size_t)b * p.h * p.wd * p.cin;
+    auto hload = [&](int slab) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) hv[j] = *reinterpret_cast<const float4*>(img + geo(j).goff + slab * BK);
+    };
+    auto hcommit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const Geo g = geo(j);
+            float4 v = hv[j];
+            if (!g.inimg) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            half4 hi, lo;
+            gemmx3::split4(v, gemmx3::ACT_SCALE, hi, lo, amax);
+            if (g.valid) {
+                const int off = g.hp * BK + gemmx3::swz(g.q >> 1, g.hp) * 8 + (g.q & 1) * 4;
+                *reinterpret_cast<half4*>(&s.ah[buf][off]) = hi;
+                *reinterpret_cast<half4*>(&s.al[buf][off]) = lo;
+            }
+        }
+    };
+    auto bdma = [&](int buf, int koff) {
+        auto bp = [&](int row, int plane) { return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * p.k + koff; };
+        gemmx3w::dma_tile<BN, NT / 64>(s.bh[buf], s.bl[buf], bp);
+    };
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    // one 16-deep k-step of tap (ky, kx): B fragments once, A fragments per 32-pixel row one block ahead of their MFMAs
+    auto kstep = [&](int abuf, int bbuf, int ky, int kx, int ks) {
+        const int brow0 = (wn * 64 + r) * BK;
+        const int bslot = gemmx3::swz(2 * ks + h, r) * 8;
+        half8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            bh[ni] = *reinterpret_cast<const half8*>(&s.bh[bbuf][brow0 + ni * 32 * BK + bslot]);
+            bl[ni] = *reinterpret_cast<const half8*>(&s.bl[bbuf][brow0 + ni * 32 * BK + bslot]);
+        }
+        auto aoff = [&](int mi) {
+            const int hp = (wm * MI + mi + ky) * HWD + r + kx;
+            return hp * BK + gemmx3::swz(2 * ks + h, hp) * 8;
+        };
+        int o = aoff(0);
+        ah[0] = *reinterpret_cast<const half8*>(&s.ah[abuf][o]);
+        al[0] = *reinterpret_cast<const half8*>(&s.al[abuf][o]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (mi + 1 < MI) {
+                o = aoff(mi + 1);
+                ah[(mi + 1) & 1] = *reinterpret_cast<const half8*>(&s.ah[abuf][o]);
+                al[(mi + 1) & 1] = *reinterpret_cast<const half8*>(&s.al[abuf][o]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi & 1], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi & 1], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi & 1], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+    const int nslab = p.cin / BK;
+    hload(0);
+    bdma(0, 0);
+    hcommit(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int c = 0;
+    for (int slab = 0; slab < nslab; ++slab) {
+        const bool more_slab = slab + 1 < nslab;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++c) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const bool more = tap < 8 || more_slab;
+            if (more) {      // the next chunk's weights: (slab, tap + 1) or (slab + 1, 0)
+                const int nt = tap < 8 ? tap + 1 : 0, ns = tap < 8 ? slab : slab + 1;
+                bdma((c + 1) & 1, nt * p.cin + ns * BK);
+            }
+            const bool fetch = tap == 0 && more_slab;
+            if (fetch) hload(slab + 1);      // behind the DMA: its wait below leaves these outstanding
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(slab & 1, c & 1, ky, kx, 0);
+            kstep(slab & 1, c & 1, ky, kx, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap == 8 && more_slab) hcommit((slab + 1) & 1);
+            if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    x3_range_flag(p.status, amax);
+    // epilogue: tile row tr = 32 y + x  ->  output pixel (b, oy0 + y, ox0 + x); bias -> BN scale / shift -> residual -> ReLU
+    const int rbase = wm * 32 * MI;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = col0 + wn * 64 + ni * 32 + r;
+        const int cc = min(col, nlast);
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float sh = p.scale ? p.shift[cc] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int tr = rbase + gemm::acc_row(mi, e, h);
+                const int oy = oy0 + (tr >> 5), ox = ox0 + (tr & 31);
+                if (oy < p.ho && ox < p.wo && col < p.cout) {
+                    const size_t o = (((size_t)b * p.ho + oy) * p.wo + ox) * p.cout + col;
+                    float v = acc[mi][ni][e] * inv + bi;
+                    if (p.scale) v = v * sc + sh;
+                    if (p.residual) v += p.residual[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[o] = v;
+                }
+            }
+    }
+}
+
 // ---------------------------------------------------------------- grouped 3x3 (VALU)
 // groups = 32, 8 in / 8 out channels per group (72-deep dot products: too thin for MFMA tiles).
 // Workgroup = 64 consecutive x-pixels x 4 output rows x 4 groups (one group per wave, so the 576
@@ -594,6 +773,21 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
         hipLaunchKernelGGL((conv_x3_kernel<MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemmx3::NT), 0, st, p, wh, wl, inv); \
     } while (0)
     static const char* force = getenv("PRAM_X3_TILE");
+    const char* halo_env = getenv("PRAM_CONV_HALO");      // "0": the per-tap staging kernel for every layer (profiling / the equality test; read per call)
+    if (ks == 3 && stride == 1 && cout >= 256 && !(force && force[0] == 'n') && !(halo_env && halo_env[0] == '0')) {
+        const int tiles_x = cdiv(p.wo, halo::TW), tiles_y = cdiv(p.ho, halo::TH);
+        p.tiles_m = batch * tiles_x * tiles_y;
+        p.tiles_n = cdiv(cout, halo::BN);
+        if ((long)p.tiles_m * p.tiles_n >= 224) {
+            static bool hattr = false;
+            if (!hattr) {
+                (void)hipFuncSetAttribute((const void*)conv3x3_x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(halo::Smem));
+                hattr = true;
+            }
+            hipLaunchKernelGGL(conv3x3_x3h_kernel, dim3(p.tiles_m * p.tiles_n), dim3(halo::NT), sizeof(halo::Smem), st, p, wh, wl, inv, tiles_x, tiles_y);
+            return pram_launch_status("pram_conv2d_nhwc_x3_f32");
+        }
+    }
     if (cout >= 256 && (long)cdiv(p.m, 256) * cdiv(cout, 256) >= 224 && !(force && force[0] == 'n')) {
         using CW = gemmx3w::Cfg<4, 2, 4>;
         const size_t shm = sizeof(gemmx3w::Smem<4, 2, 4>);

@@ -510,3 +510,28 @@ print("RCCL_ONE_RANK_OK")
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+# ------------------------------------------------------------------------------------------------ 3x3 conv with the window in LDS
+@pytest.mark.parametrize("shape", [(4, 120, 160, 256, 256), (12, 60, 80, 128, 256), (12, 37, 45, 64, 512), (16, 120, 160, 32, 256)])
+def test_conv3x3_halo_equals_chunked(dev, shape, monkeypatch):
+    """3x3 / stride-1 layers with >= 256 output channels keep the input window of a workgroup resident in LDS (staged and split once
+    per 32-channel slab instead of once per tap): same K order, same products per accumulator -> the SAME bits as the per-tap kernel
+    (PRAM_CONV_HALO=0), with bias, BatchNorm scale / shift, residual and ReLU, on whole and on ragged tiles; both against fp64."""
+    B, Hh, Ww, cin, cout = shape
+    x = W.normal(41, f"hc/x{shape}", (B, Hh, Ww, cin), 1.0).to(dev)
+    w = W.normal(41, f"hc/w{shape}", (cout, 3, 3, cin), (9 * cin) ** -0.5).to(dev)
+    bias = W.normal(41, "hc/b", (cout,), 0.1).to(dev)
+    sc = (1.0 + W.normal(41, "hc/s", (cout,), 0.1)).to(dev)
+    sh = W.normal(41, "hc/t", (cout,), 0.1).to(dev)
+    res = W.normal(41, f"hc/r{shape}", (B, Hh, Ww, cout), 1.0).to(dev)
+    for kw in (dict(relu=False), dict(scale=sc, shift=sh, residual=res, relu=True)):
+        monkeypatch.setenv("PRAM_CONV_HALO", "1")
+        a = ops.conv2d_nhwc(x, w, bias, kw.get("scale"), kw.get("shift"), residual=kw.get("residual"), ks=3, relu=kw["relu"], precision="x3")
+        monkeypatch.setenv("PRAM_CONV_HALO", "0")
+        b = ops.conv2d_nhwc(x, w, bias, kw.get("scale"), kw.get("shift"), residual=kw.get("residual"), ks=3, relu=kw["relu"], precision="x3")
+        assert torch.equal(a, b)
+        want = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+        if "scale" in kw:
+            want = torch.relu(want * sc.double() + sh.double() + res.double())
+        assert float((a.double() - want).abs().max()) < 2e-5
