@@ -34,6 +34,21 @@ def test_bench_one_gpu_line(hip_lib):
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches_per_step"] == 33
 
 
+def test_bench_latency_mode_line(hip_lib):
+    """`--latency`: one query per step, nothing in flight, the step replayed from captured graphs on two streams, 512-key attention
+    chunks (split launches); the parity gate runs on the same arithmetic."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--latency", "--steps", "8", "--warmup", "3", "--cpu-queries", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["queries_per_step"] == 1 and c["batches_in_flight_per_gpu"] == 1 and c["hipgraph_replay"] is True
+    assert c["attention_chunk_keys"] == 512 and "latency mode" in c["workload"]
+    assert d["parity"]["ok"] and d["parity"]["match"]["indices_identical"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"] and d["ms_per_step"] < 20.0
+    assert d["range_guard"]["x3_range_exceeded"] is False
+
+
 def test_bench_two_ranks_control_flow(hip_lib):
     env = dict(os.environ, PRAM_BENCH_ONE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
