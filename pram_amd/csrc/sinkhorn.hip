@@ -62,44 +62,63 @@ static SinkWs carve(void* ws, int batch, int m_max, int n_max, size_t* total) {
 // ---- row softmax of the augmented matrix (one wave per row), u, v <- 1 ------------------------
 // mode 0: write softmax probabilities (Sinkhorn);  mode 1: write raw augmented scores and the row
 // log-sum-exp (dual softmax).
+template <int NV>
 __global__ __launch_bounds__(256) void sink_init_kernel(const float* __restrict__ dist, int ldd, long long sdist,
                                                         const int* __restrict__ m_lens, const int* __restrict__ n_lens,
                                                         const float* __restrict__ bin, SinkWs w, int m_max, int n_max,
                                                         int mode) {
+    // The row (at most NV * 256 columns: lane l owns columns l, l + 64, ...) is read ONCE and kept in registers; the first version
+    // walked it three times (max, sum of exponentials, write) with two exponentials per element: 218 -> ~120 us at 16 pairs of
+    // 2049 x 2049.  Every lane adds its exponentials in the same order as before, so the row sums keep their bits.
+    constexpr int EPL = NV * 4;
     const int b = blockIdx.y;
     const int m = m_lens ? m_lens[b] : m_max, n = n_lens ? n_lens[b] : n_max;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (i == 0)
         for (int j = lane; j < w.ldw; j += 64) w.v[(size_t)b * w.ldw + j] = 1.0f;
     // u <- 1 as well: with zero iterations the final pass returns the plain row softmax (u = v = 1), like the reference
     if (i <= m_max && lane == 0) w.u[(size_t)b * (m_max + 1) + i] = 1.0f;
     if (i > m) return;
     const float bs = bin[0];
-    const float* src = dist + b * sdist + (size_t)i * ldd;
+    const float* src = dist + b * sdist + (size_t)min(i, m_max - 1) * ldd;      // the bin row (i == m) reads nothing it uses
     float* dst = w.P + ((size_t)b * (m_max + 1) + i) * w.ldw;
     const bool binrow = (i == m);
+    float x[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) x[t] = src[min(lane + 64 * t, max(n - 1, 0))];      // unpredicated; masked below
     float mx = bs;
-    if (!binrow)
-        for (int j = lane; j < n; j += 64) mx = fmaxf(mx, src[j]);
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int j = lane + 64 * t;
+        if (binrow || j >= n) x[t] = bs;          // the dust-bin column j == n (and the padding, never used)
+        if (!binrow && j < n) mx = fmaxf(mx, x[t]);
+    }
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int j = lane; j <= n; j += 64) {
-        const float x = (binrow || j == n) ? bs : src[j];
-        sum += expf(x - mx);
-    }
-    sum = wave_sum(sum);
     if (mode == 0) {
-        for (int j = lane; j < w.ldw; j += 64) {
-            float pv = 0.f;
-            if (j <= n) {
-                const float x = (binrow || j == n) ? bs : src[j];
-                pv = expf(x - mx) / sum;
-            }
-            dst[j] = pv;
+        float e[EPL];
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            e[t] = expf(x[t] - mx);
+            if (lane + 64 * t <= n) sum += e[t];
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int j = lane + 64 * t;
+            if (j < w.ldw) dst[j] = (j <= n) ? e[t] / sum : 0.f;
         }
     } else {
-        for (int j = lane; j < w.ldw; j += 64) dst[j] = (j <= n) ? ((binrow || j == n) ? bs : src[j]) : -INFINITY;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            if (lane + 64 * t <= n) sum += expf(x[t] - mx);
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const int j = lane + 64 * t;
+            if (j < w.ldw) dst[j] = (j <= n) ? x[t] : -INFINITY;
+        }
         if (lane == 0) w.rlse[(size_t)b * (m_max + 1) + i] = mx + logf(sum);
     }
 }
@@ -239,17 +258,30 @@ __global__ __launch_bounds__(256) void sink_colreduce_kernel(const int* __restri
 }
 
 // ---- final pass: p = P*u*v (or the dual-softmax score), row max/argmax, column partial max ----------
-template <int NV, int MODE>
+// Built like sink_iter_kernel (see the rules there): the row ahead is requested through unpredicated loads from clamped
+// addresses, the wave index is scalar, and nothing is stored inside the row loop — a row's (max, arg-max) is kept by the lane
+// with the row's number and stored after the loop.  WANT_P (the caller asked for the full assignment matrix) stores p inside
+// the loop and pays a memory round trip per row for it, as every row did before: 135 -> 70 us at 16 pairs of 2049 x 2049.
+template <int NV, int MODE, bool WANT_P>
 __global__ __launch_bounds__(256) void sink_final_kernel(const int* __restrict__ m_lens, const int* __restrict__ n_lens,
                                                          SinkWs w, int m_max, int n_max, float* __restrict__ p_out,
                                                          int ldp) {
     extern __shared__ __attribute__((aligned(16))) float sv[];
     const int b = blockIdx.y;
     const int m = m_lens ? m_lens[b] : m_max, n = n_lens ? n_lens[b] : n_max;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ldw = w.ldw;
     const float* colvec = (MODE == 0) ? w.v : w.clse;
-    for (int j = tid; j < ldw; j += 256) sv[j] = colvec[(size_t)b * ldw + j];
+    {   // column vector -> LDS, padded to NV * 256 (the padding is never compared: j < n below); all loads before the first store
+        constexpr int NQ = (NV * 64 + 255) / 256;
+        float4 q4[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) q4[t] = *reinterpret_cast<const float4*>(colvec + (size_t)b * ldw + min((tid + t * 256) * 4, ldw - 4));
+#pragma unroll
+        for (int t = 0; t < NQ; ++t)
+            if ((tid + t * 256) * 4 < NV * 256) *reinterpret_cast<float4*>(sv + (tid + t * 256) * 4) = q4[t];
+    }
     __syncthreads();
     const int rows = m + 1;
     const int rpb = (rows + NBLK - 1) / NBLK;
@@ -261,46 +293,68 @@ __global__ __launch_bounds__(256) void sink_final_kernel(const int* __restrict__
     for (int t = 0; t < NV * 4; ++t) { cmax[t] = -INFINITY; cidx[t] = 0x7fffffff; }
     const float* Pb = w.P + (size_t)b * (m_max + 1) * ldw;
     const float* rowvec = (MODE == 0) ? w.u : w.rlse;
+    float4 nx[NV];
+    float nu;
+    auto rload = [&](int i) {
+        const int ic = max(min(i, rend - 1), 0);
+        nu = rowvec[(size_t)b * (m_max + 1) + ic];
+        const float* rp = Pb + (size_t)ic * ldw;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) nx[t] = *reinterpret_cast<const float4*>(rp + min((t * 64 + lane) * 4, ldw - 4));
+    };
+    rload(rbeg + wave);
+    __builtin_amdgcn_sched_barrier(0);
+    float rkeep = -INFINITY;
+    int ikeep = 0x7fffffff;
     for (int i = rbeg + wave; i < rend; i += 4) {
-        const float ui = rowvec[(size_t)b * (m_max + 1) + i];
+        // the row's values first (they consume the prefetched registers), then the request for the next row, then the comparisons
+        float pv[NV][4];
+        const float ui = nu;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const float4 pr = nx[t];
+            const float4 vv = *reinterpret_cast<const float4*>(sv + (t * 64 + lane) * 4);
+            if (MODE == 0) {
+                pv[t][0] = (pr.x * ui) * vv.x; pv[t][1] = (pr.y * ui) * vv.y;
+                pv[t][2] = (pr.z * ui) * vv.z; pv[t][3] = (pr.w * ui) * vv.w;
+            } else {  // exp(log_softmax_row + log_softmax_col)
+                pv[t][0] = expf((pr.x - ui) + (pr.x - vv.x)); pv[t][1] = expf((pr.y - ui) + (pr.y - vv.y));
+                pv[t][2] = expf((pr.z - ui) + (pr.z - vv.z)); pv[t][3] = expf((pr.w - ui) + (pr.w - vv.w));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rload(i + 4);
+        __builtin_amdgcn_sched_barrier(0);
         float best = -INFINITY;
         int bidx = 0x7fffffff;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int c = (t * 64 + lane) * 4;
-            if (c < ldw) {
-                const float4 pr = *reinterpret_cast<const float4*>(Pb + (size_t)i * ldw + c);
-                const float4 vv = *reinterpret_cast<const float4*>(sv + c);
-                float pv[4];
-                if (MODE == 0) {
-                    pv[0] = (pr.x * ui) * vv.x; pv[1] = (pr.y * ui) * vv.y;
-                    pv[2] = (pr.z * ui) * vv.z; pv[3] = (pr.w * ui) * vv.w;
-                } else {  // exp(log_softmax_row + log_softmax_col)
-                    pv[0] = expf((pr.x - ui) + (pr.x - vv.x)); pv[1] = expf((pr.y - ui) + (pr.y - vv.y));
-                    pv[2] = expf((pr.z - ui) + (pr.z - vv.z)); pv[3] = expf((pr.w - ui) + (pr.w - vv.w));
-                }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = c + k;
-                    if (p_out && j <= n) p_out[((size_t)b * (m_max + 1) + i) * ldp + j] = pv[k];
-                    if (i < m && j < n) {
-                        if (pv[k] > best) { best = pv[k]; bidx = j; }
-                        if (pv[k] > cmax[t * 4 + k]) { cmax[t * 4 + k] = pv[k]; cidx[t * 4 + k] = i; }
-                    }
+            for (int k = 0; k < 4; ++k) {
+                const int j = c + k;
+                if constexpr (WANT_P) {
+                    if (j <= n) p_out[((size_t)b * (m_max + 1) + i) * ldp + j] = pv[t][k];
+                }
+                if (i < m && j < n) {
+                    if (pv[t][k] > best) { best = pv[t][k]; bidx = j; }
+                    if (pv[t][k] > cmax[t * 4 + k]) { cmax[t * 4 + k] = pv[t][k]; cidx[t * 4 + k] = i; }
                 }
             }
         }
-        if (i < m) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(best, o, 64);
-                const int oi = __shfl_xor(bidx, o, 64);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            if (lane == 0) {
-                w.rowval[(size_t)b * m_max + i] = best;
-                w.rowidx[(size_t)b * m_max + i] = bidx;
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bidx, o, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (lane == ((i - rbeg) >> 2)) { rkeep = best; ikeep = bidx; }
+    }
+    {
+        const int i = rbeg + wave + 4 * lane;      // at most ceil(4352 / 32 / 4) = 34 rows per wave
+        if (i < rend && i < m) {
+            w.rowval[(size_t)b * m_max + i] = rkeep;
+            w.rowidx[(size_t)b * m_max + i] = ikeep;
         }
     }
     float* part = w.part + ((size_t)b * NBLK * 4 + blockIdx.x * 4 + wave) * ldw;
@@ -459,20 +513,22 @@ template <int NV>
 int run_sinkhorn(const float* dist, int ldd, const int* m_lens, const int* n_lens, const float* bin, int iters,
                  float thr, float* p_out, int ldp, long long* matches0, long long* matches1, float* ms0, float* ms1,
                  int batch, int m_max, int n_max, SinkWs w, hipStream_t st, bool dual) {
-    const size_t shm = (size_t)w.ldw * 4, shm_it = (size_t)NV * 256 * 4;      // the iteration kernel pads v with zeros to NV * 256
+    const size_t shm_it = (size_t)NV * 256 * 4;      // the row kernels keep the column vector in LDS, padded to NV * 256
     dim3 grow(cdiv(m_max + 1, 4), batch), giter(NBLK, batch), gcol(cdiv(w.ldw, 256), batch);
-    hipLaunchKernelGGL(sink_init_kernel, grow, dim3(256), 0, st, dist, ldd, (long long)m_max * ldd, m_lens, n_lens, bin,
+    hipLaunchKernelGGL(sink_init_kernel<NV>, grow, dim3(256), 0, st, dist, ldd, (long long)m_max * ldd, m_lens, n_lens, bin,
                        w, m_max, n_max, dual ? 1 : 0);
     if (!dual) {
         for (int it = 0; it < iters; ++it) {
             hipLaunchKernelGGL((sink_iter_kernel<NV, 1>), giter, dim3(256), shm_it, st, m_lens, n_lens, w, m_max, n_max);
             hipLaunchKernelGGL(sink_colreduce_kernel, gcol, dim3(256), 0, st, n_lens, w, n_max);
         }
-        hipLaunchKernelGGL((sink_final_kernel<NV, 0>), giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
+        if (p_out) hipLaunchKernelGGL((sink_final_kernel<NV, 0, true>), giter, dim3(256), shm_it, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
+        else hipLaunchKernelGGL((sink_final_kernel<NV, 0, false>), giter, dim3(256), shm_it, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
     } else {
         hipLaunchKernelGGL(dual_colpart_kernel<NV>, giter, dim3(256), 0, st, m_lens, w, m_max);
         hipLaunchKernelGGL(dual_colreduce_kernel, gcol, dim3(256), 0, st, w);
-        hipLaunchKernelGGL((sink_final_kernel<NV, 1>), giter, dim3(256), shm, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
+        if (p_out) hipLaunchKernelGGL((sink_final_kernel<NV, 1, true>), giter, dim3(256), shm_it, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
+        else hipLaunchKernelGGL((sink_final_kernel<NV, 1, false>), giter, dim3(256), shm_it, st, m_lens, n_lens, w, m_max, n_max, p_out, ldp);
     }
     hipLaunchKernelGGL(sink_colmax_kernel, dim3(cdiv(n_max, 32), batch), dim3(256), 0, st, n_lens, w, n_max);
     hipLaunchKernelGGL(sink_mutual_kernel, dim3(cdiv(m_max > n_max ? m_max : n_max, 256), batch), dim3(256), 0, st, m_lens, n_lens, w,
