@@ -322,7 +322,8 @@ def attention_roofline(probe, precision, dev, step_ms):
     both directions (nets/gml.py:175-179) while the kernel, like every flash formulation, multiplies it once per direction: the
     launch executes 4/3 of the algorithmic work and that shows up as a LOWER fraction, not as extra credit.
     The split-fp16 kernel issues `mfma_per_tile` v_mfma_f32_32x32x16_f16 per 64-key tile where a single-product fp16 attention
-    needs 16 (the library reports 40 = 2.5 per product from 1024 keys on, 48 = 3 below): the fp32-class ceiling of THIS kernel is
+    needs 16 (the library reports what the launch issues: 48 = 3 per product by default; 40 = 2.5 from 1024 keys on when
+    pram_attention_x3_set_p_split(0) carries the probabilities as one fp16): the fp32-class ceiling of THIS kernel is
     the fp16 MFMA peak divided by that multiplier."""
     t_ms, alg, launched, executed = 0.0, 0.0, 0.0, 0.0
     for ql, kl, mm, nn, hh, bb, e0, e1, kind, mfma_tile in probe:
@@ -506,7 +507,7 @@ def main():
                     help="also time, in the same run (3 steps each), AdaGML, the exact-fp32 path, the secondary 512 x 1024 matcher "
                          "shape and the one-query latency, and report them as 'alt' (auto: on for the default 1-GPU configuration)")
     ap.add_argument("--attn-chunk-keys", type=int, default=None,
-                    help="keys per chunk of the split-fp16 attention (pram_attention_x3_set_chunk_keys; default: the library's 2048, "
+                    help="keys per chunk of the split-fp16 attention (pram_attention_x3_set_chunk_keys; default: the library's 4096 = one chunk for every shipped shape, "
                          "512 with --latency so that one-frame launches split along the keys and fill the chip)")
     ap.add_argument("--precision", default=None, choices=["f32", "x3", "f16"],
                     help="MFMA path of the three matrix families: f32 = v_mfma_f32_32x32x2_f32 (exact fp32 products); "
@@ -559,10 +560,10 @@ def main():
     # one-frame launch: 4.19 -> 4.13 ms per query); PRAM_BENCH_SPLIT_TARGET overrides (profiling).  Never changes a result bit.
     split_target = int(os.environ.get("PRAM_BENCH_SPLIT_TARGET", "512" if args.latency else "-1"))
     _plib.load().pram_attention_x3_set_split_target(split_target)
-    if ops.attention_precision != ops.gemm_precision:
-        raise SystemExit(f"bench.py: PRAM_GEMM_PRECISION={ops.gemm_precision} and PRAM_ATTENTION_PRECISION={ops.attention_precision} "
+    if ops.attn_prec() != ops.gemm_prec():
+        raise SystemExit(f"bench.py: PRAM_GEMM_PRECISION={ops.gemm_prec()} and PRAM_ATTENTION_PRECISION={ops.attn_prec()} "
                          f"differ — the line reports ONE arithmetic (use --precision / PRAM_PRECISION)")
-    precision = ops.gemm_precision
+    precision = ops.gemm_prec()
     use_graph = args.graph == "on" or (args.graph == "auto" and (world > 1 or args.latency))
 
     if args.batch_total > 0:
@@ -621,7 +622,10 @@ def main():
         if n_matches < 0.1 * n_inliers:
             raise SystemExit(f"bench.py: degenerate matcher workload ({n_matches} matches for {n_inliers} planted twins)")
     # range guard of the split-fp16 path: the timed steps ran "deferred" (several in flight) — read it once, now
-    range_hit = ops.x3_range_exceeded(dev) if precision == "x3" else False
+    # (armed by what was LAUNCHED, not by the precision setting: the fp16 path runs a few split-fp16 kernels on purpose — GML's
+    # matching descriptors and their score matrix — and their range is checked like everybody's)
+    x3_ran = ops.x3_launched(dev)
+    range_hit = ops.x3_range_exceeded(dev) if x3_ran else False
 
     # ---- roofline of the dominant kernel (attention), one extra instrumented EAGER step, HIP events on the launch stream
     lanes_saved, graphs_saved = job.lanes, job.graphs
@@ -668,7 +672,7 @@ def main():
             try:
                 j = Job(dev, 0, 1, 0, Bq, **cfg)
                 t, _ = j.timed(steps_, warm_, sync_all)
-                hit = ops.x3_range_exceeded(dev) if (cfg["precision"] or precision) == "x3" else False
+                hit = ops.x3_range_exceeded(dev) if ops.x3_launched(dev) else False
                 alt[name] = {"queries_per_s": round(Bq * steps_ / t, 2), "ms_per_step": round(t / steps_ * 1e3, 3), "steps": steps_, "what": note}
                 if hit:
                     alt[name]["x3_range_exceeded"] = True
@@ -693,7 +697,8 @@ def main():
     if rank == 0:
         total_q = total_per_step * steps
         dtype = {"f32": "f32", "x3": "f32 results via split-fp16 MFMA (f16 x3 products, f32 accumulate)",
-                 "f16": "f16 operands / f32 accumulate: BASELINE C5 'fp16 MFMA path', NOT the fp32 parity configuration"}[precision]
+                 "f16": "f16 operands / f32 accumulate: BASELINE C5 'fp16 MFMA path', NOT the fp32 parity configuration"
+                        + ("; the matcher's final descriptor projection and score matrix run split-fp16 (x3) on purpose" if x3_ran else "")}[precision]
         rk = args.ref_kpts or args.kpts
         line = {
             "metric": f"query images/sec (640x480, {args.kpts} kpts, {'7Scenes ' if args.n_class == 113 else ''}nc{args.n_class})",
@@ -711,7 +716,7 @@ def main():
                        "keypoints_found": counts[:4], "parallelism": f"query-sharded x{world}, one all-gather of result records",
                        "matches_last_step": n_matches, "matches_correct_last_step": n_correct},
             "roofline": roofline,
-            "range_guard": {"x3_range_exceeded": bool(range_hit),
+            "range_guard": {"x3_range_exceeded": bool(range_hit), "split_fp16_kernels_in_step": bool(x3_ran),
                             "policy": "deferred: the status word is read once after the timed region (steps in flight); set = the line is void"},
         }
         if world > 1:

@@ -87,6 +87,16 @@ int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int 
                         float* out, int ldo, int m, int n, float alpha, int flags,
                         const float* rot_cos, const float* rot_sin, int rot_cols, void* stream);
 
+/* pram_linear_f16_f32 on a ragged token matrix, as pram_linear_ragged_f32 / pram_linear_x3_ragged_f32: rows are sequences of
+ * t_pad rows, sequence s has lens[s] (device int32) valid ones; output tiles without a valid row are skipped and only valid rows
+ * are stored (`out` may be a persistent buffer whose other rows belong to someone else: AdaGML commits the matching descriptors
+ * of the pairs that stop at a layer, nets/adagml.py:386-396).  lens == NULL: pram_linear_f16_f32. */
+int pram_linear_f16_ragged_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                               const void* w16, const float* bias, const float* residual, int ldr,
+                               float* out, int ldo, int m, int n, float alpha, int flags,
+                               const float* rot_cos, const float* rot_sin, int rot_cols,
+                               const int* lens, int t_pad, void* stream);
+
 /* pram_linear_f16_f32 that also (or only: out may be NULL) writes the result rounded to fp16 — the q / k / v operand
  * of pram_attention_h16_f32, which would otherwise round the fp32 result itself while staging it (same values). */
 int pram_linear_f16_h16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
@@ -216,8 +226,10 @@ int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, c
  * sites as pram_attention_f32).  q / k are row-major split planes written by pram_linear_x3_f32 (value * 16 = hi + lo,
  * ld* in halves, multiples of 8; heads are 64-wide column blocks); vt_hi / vt_lo are the TRANSPOSED value planes of the
  * key side built by pram_attention_x3_vt: [batch][heads][64][tv], tv = n_max rounded up to 64.  S = K Q^T and O = P V are
- * fp16 MFMAs with fp32 accumulation: three per product for the scores; two per product for P V from 1024 keys on (the
- * probabilities enter as one fp16), three below (pram_attention_x3_mfma_per_tile).  Output fp32.
+ * fp16 MFMAs with fp32 accumulation: three per product for the scores and, by default, three per product for P V (the
+ * probabilities enter as two fp16 parts like every other operand: 48 MFMAs per 64-key tile and 32-query wave);
+ * pram_attention_x3_set_p_split(0) carries the probabilities as ONE fp16 from 1024 keys on (two MFMAs per P V product, 40 per
+ * tile — not the default, see below); pram_attention_x3_mfma_per_tile reports what a launch issues.  Output fp32.
  * kv_shift as in pram_attention_h16_f32 (cross attention: batch = 2 * pairs, kv_shift = pairs).
  * Key chunks: from 1024 keys on the keys are reduced in chunks (pram_attention_x3_set_chunk_keys: default 4096 keys, i.e. one chunk for every shipped configuration), each chunk
  * normalised and all chunks folded in chunk order.  One workgroup normally walks all chunks of its 128 query rows and folds them

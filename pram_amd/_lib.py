@@ -25,6 +25,7 @@ _SIGS = {
     "pram_read_status_word": (I, [P, I, P]),
     "pram_linear_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_f16_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
+    "pram_linear_f16_ragged_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P, I, P]),
     "pram_linear_f16_h16": (I, [P, I, I, P, I, I, P, P, P, I, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_x3_f32": (I, [P, I, I, P, I, I, P, P, F, P, P, I, P, I, P, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_ragged_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P, I, P]),

@@ -405,6 +405,10 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
     const int tid = threadIdx.x;
     const int arow = tid >> 4, akq = tid & 15, brow = tid >> 3, bsl = tid & 7;
     const int row0 = tm * BM, col0 = tn * BN;
+    // ragged token matrices (pram_linear_f16_ragged_f32): tiles without a valid row are skipped, the epilogue stores valid rows only.
+    // Rows beyond a sequence's length are multiplied like the others (whatever they hold stays in their own output rows, which
+    // are never stored).  Not for the V^T-writing projection: its planes need their zeros beyond every sequence's length.
+    if (!p.vt_hi && !tile_has_rows(p.lens, p.t_pad, row0, BM, p.m)) return;
     const int mlast = p.m - 1, nlast = p.n - 1;
     auto la = [&](int pp, int kt) -> float4 {
         const int rc = min(row0 + arow + 16 * pp, mlast);
@@ -1013,26 +1017,47 @@ extern "C" int pram_linear_x3_qkv_f32(const float* a0, int lda0, int k0, const v
                           out_lo, ldo16, m, n, 1.0f, flags, rot_cos, rot_sin, rot_cols, stream);
 }
 
-extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
-                                   const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
-                                   float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
-                                   void* stream) {
-    PRAM_REQUIRE(a0 && w16 && out, "pram_linear_f16_f32: null pointer");
-    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "pram_linear_f16_f32: bad sizes");
-    PRAM_REQUIRE((k0 + k1) % 8 == 0 && lda0 % 4 == 0, "pram_linear_f16_f32: K must be a multiple of 8, lda of 4");
-    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemm16::BK == 0 && lda1 % 4 == 0), "pram_linear_f16_f32: concat needs k0 %% 64 == 0");
+static int linear_f16_f32_impl(const char* who, const int* lens, int t_pad, const float* a0, int lda0, int k0, const float* a1, int lda1, int k1,
+                               const void* w16, const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                               float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols, void* stream) {
+    PRAM_REQUIRE(a0 && w16 && out, "%s: null pointer", who);
+    PRAM_REQUIRE(m >= 0 && n > 0 && k0 > 0 && k1 >= 0, "%s: bad sizes", who);
+    PRAM_REQUIRE((k0 + k1) % 8 == 0 && lda0 % 4 == 0, "%s: K must be a multiple of 8, lda of 4", who);
+    PRAM_REQUIRE(k1 == 0 || (a1 && k0 % gemm16::BK == 0 && lda1 % 4 == 0), "%s: concat needs k0 %% 64 == 0", who);
     if (flags & PRAM_LIN_ROTARY)
-        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_f16_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
+        PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "%s: rotary needs cos/sin and rot_cols %% 64 == 0", who);
     if (m == 0) return PRAM_OK;
     LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
               rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0};
+    p.lens = lens;
+    p.t_pad = t_pad;
     int mi, wn;
     gemm::choose_tile(m, n, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
     const _Float16* w = (const _Float16*)w16;
     if (wn == 2) { if (mi == 2) launch_linear_f16_t<2, 2>(p, w, st); else launch_linear_f16_t<1, 2>(p, w, st); }
     else launch_linear_f16_t<1, 1>(p, w, st);      // 128-row tiles for narrow outputs: the 256-row instantiation spills (43 registers) on this path
-    return pram_launch_status("pram_linear_f16_f32");
+    return pram_launch_status(who);
+}
+
+extern "C" int pram_linear_f16_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
+                                   const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                                   float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                                   void* stream) {
+    return linear_f16_f32_impl("pram_linear_f16_f32", nullptr, 0, a0, lda0, k0, a1, lda1, k1, w16, bias, residual, ldr, out, ldo, m, n, alpha, flags,
+                               rot_cos, rot_sin, rot_cols, stream);
+}
+
+/* pram_linear_f16_f32 on a ragged token matrix (as pram_linear_x3_ragged_f32 / pram_linear_ragged_f32): rows are sequences of
+   t_pad rows, sequence s has lens[s] (device int32) valid ones; output tiles without a valid row are skipped and only valid rows
+   are stored — `out` may be a persistent buffer whose other rows belong to someone else (AdaGML's matching descriptors). */
+extern "C" int pram_linear_f16_ragged_f32(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,
+                                          const float* bias, const float* residual, int ldr, float* out, int ldo, int m, int n,
+                                          float alpha, int flags, const float* rot_cos, const float* rot_sin, int rot_cols,
+                                          const int* lens, int t_pad, void* stream) {
+    PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_f16_ragged_f32: lens needs t_pad > 0");
+    return linear_f16_f32_impl("pram_linear_f16_ragged_f32", lens, t_pad, a0, lda0, k0, a1, lda1, k1, w16, bias, residual, ldr, out, ldo, m, n, alpha,
+                               flags, rot_cos, rot_sin, rot_cols, stream);
 }
 
 extern "C" int pram_linear_f16_h16(const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const void* w16,

@@ -422,7 +422,10 @@ __global__ __launch_bounds__(256) void sink_mutual_kernel(const int* __restrict_
     if (t < m_max) {
         long long mi = -1;
         float sc = 0.f;
-        if (t < m && n > 0) {
+        // A row / column whose scores are all NaN (a non-finite operand upstream) never wins a comparison and keeps the "no index"
+        // sentinel: it is reported unmatched with score 0 (torch.max would name the first NaN; every `> p` test on it fails there
+        // too, so the MATCHES agree) — and is never used as an address.
+        if (t < m && n > 0 && (unsigned)rowidx[t] < (unsigned)n) {
             const int j = rowidx[t];
             const bool mutual = colidx[j] == t;
             sc = mutual ? rowval[t] : 0.f;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256) void sink_mutual_kernel(const int* __restrict_
     if (t < n_max) {
         long long mj = -1;
         float sc = 0.f;
-        if (t < n && m > 0) {
+        if (t < n && m > 0 && (unsigned)colidx[t] < (unsigned)m && (unsigned)rowidx[colidx[t]] < (unsigned)n) {
             const int i = colidx[t];
             const bool mutual1 = rowidx[i] == t;
             const bool mutual0 = colidx[rowidx[i]] == i;

@@ -79,7 +79,7 @@ def pack_cross_block(sd: Dict[str, torch.Tensor], prefix: str, device) -> Dict[s
 
 def _half_path() -> bool:
     """both the token GEMMs and the attention run on the fp16 MFMA path (BASELINE C5): q / k / v can travel as fp16"""
-    return ops.gemm_precision == "f16" and ops.attention_precision == "f16"
+    return ops.gemm_prec() == "f16" and ops.attn_prec() == "f16"
 
 
 import os as _os
@@ -94,7 +94,7 @@ FUSED_VT = _os.environ.get("PRAM_FUSED_VT", "1") != "0"      # the projection ep
 
 def _split_path() -> bool:
     """both families on the split-fp16 path: the projection hands q / k / v over as (hi, lo) fp16 planes"""
-    return ops.gemm_precision == "x3" and ops.attention_precision == "x3"
+    return ops.gemm_prec() == "x3" and ops.attn_prec() == "x3"
 
 
 def _cols(planes, lo: int, hi: int):
@@ -104,7 +104,7 @@ def _cols(planes, lo: int, hi: int):
 def _mlp_tail(x: torch.Tensor, ctx: torch.Tensor, p: Dict[str, torch.Tensor], lens=None, T: int = 0) -> torch.Tensor:
     """x + mlp(cat[x, proj(ctx)])  (nets/segnetvit.py:104-106), proj folded into mlp.0.  lens / T: ragged sequences — tiles of
     rows beyond every sequence's length are skipped (their rows are never read downstream)."""
-    if ops.gemm_precision == "x3" and FUSED_MLP:
+    if ops.gemm_prec() == "x3" and FUSED_MLP:
         return ops.mlp_tail(x, p["mlp0_w"], p["mlp0_b"], p["mlp.1.weight"], p["mlp.1.bias"], p["mlp.3.weight"], p["mlp.3.bias"],
                             x2=ctx, residual=x, lens=lens, t_pad=T)
     h = ops.linear(x, p["mlp0_w"], p["mlp0_b"], x2=ctx, lens=lens, t_pad=T)
@@ -141,7 +141,7 @@ def self_block(x: torch.Tensor, p: Dict[str, torch.Tensor], cos: torch.Tensor, s
         _, h16 = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), half_copy="only")
         vt = ops.value_t16(h16[:, 2 * hid:], S, HEADS, T, lens)
         ctx = ops.attention_h16t(h16[:, :hid], h16[:, hid:2 * hid], vt, S, HEADS, T, T, scale, lens, lens)
-        return _mlp_tail(x, ctx, p)
+        return _mlp_tail(x, ctx, p, lens, T)
     qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], rotary=(cos, sin, 2 * HEADS * DH), lens=lens, t_pad=T)
     q, k, v = qkv[:, :hid], qkv[:, hid:2 * hid], qkv[:, 2 * hid:]
     if want_colmean:
@@ -179,7 +179,7 @@ def cross_block(x: torch.Tensor, p: Dict[str, torch.Tensor], B: int, T: int, len
         qk16, v16 = h16[:, :hid], h16[:, hid:]
         vt = ops.value_t16(v16, 2 * B, HEADS, T, lens)
         ctx = ops.attention_h16t(qk16, qk16, vt, 2 * B, HEADS, T, T, scale, lens, lens, kv_shift=B)
-        return _mlp_tail(x, ctx, p)
+        return _mlp_tail(x, ctx, p, lens, T)
     qkv = ops.linear(x, p["qkv_w"], p["qkv_b"], lens=lens, t_pad=T)          # [2B*T, 512] = [qk | v]
     qk, v = qkv[:, :hid], qkv[:, hid:]
     # one launch for both directions: sequence s attends to sequence (s + B) mod 2B
@@ -210,7 +210,7 @@ def with_model_precision(fn):
 
 class PackedCache:
     """Mixin: device-side packed weights, rebuilt after load_state_dict / .to() / .cuda(); per-model MFMA path."""
-    precision: Optional[str] = None      # "f32" | "x3" | "f16"; None follows ops.gemm_precision / ops.attention_precision
+    precision: Optional[str] = None      # "f32" | "x3" | "f16"; None follows ops.gemm_prec() / ops.attn_prec()
 
     def set_precision(self, p: Optional[str]):
         self.precision = None if p is None else ops._check_precision(p)

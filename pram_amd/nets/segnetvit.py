@@ -119,7 +119,7 @@ class SegNetViT(blk.PackedCache, nn.Module):
         kw = dict(lens=lens, t_pad=N)      # ragged like the layers: rows beyond a frame's keypoint count are never read or written
         # the logits of rows beyond a frame's keypoint count read zero (they are the tensor the caller sees), not leftovers
         o0 = None if lens is None else ops._filled((B * N, P["seg3_w"].shape[0]), x.device)
-        if ops.gemm_precision == "x3" and blk.FUSED_MLP and P["seg3_w"].shape[0] > 64:
+        if ops.gemm_prec() == "x3" and blk.FUSED_MLP and P["seg3_w"].shape[0] > 64:
             out = ops.mlp_tail(x, P["seg0_w"], P["seg0_b"], P["seg1_w"], P["seg1_b"], P["seg3_w"], P["seg3_b"], out=o0, **kw)
         else:
             h = ops.linear(x, P["seg0_w"], P["seg0_b"], **kw)
@@ -129,5 +129,6 @@ class SegNetViT(blk.PackedCache, nn.Module):
         if self.with_sc:      # three outputs: narrower than the fused tail takes
             h = ops.linear(x, P["sc0_w"], P["sc0_b"], **kw)
             ops.layernorm_gelu_(h, P["sc1_w"], P["sc1_b"], **kw)
-            output['sc'] = ops.linear(h, P["sc3_w"], P["sc3_b"], **kw).view(B, N, 3)
+            s0 = None if lens is None else ops._filled((B * N, 3), x.device)      # zeros beyond a frame's keypoint count, like 'prediction'
+            output['sc'] = ops.linear(h, P["sc3_w"], P["sc3_b"], out=s0, **kw).view(B, N, 3)
         return output

@@ -57,7 +57,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     of attention_h16.
     split_out (x3 path only): "also" -> (out fp32, (hi, lo)), "only" -> (None, (hi, lo)): the result * 16 as two fp16 planes,
     the operand format of attention_x3.
-    lens / t_pad (f32 and x3 paths): ragged token matrix — rows are sequences of t_pad rows with lens[s] valid ones; output tiles
+    lens / t_pad (every path; with half_copy the fp16 copy is dense): ragged token matrix — rows are sequences of t_pad rows with lens[s] valid ones; output tiles
     without a valid row are skipped and left untouched (and only valid rows are stored).
     out_planes (with split_out): a (hi, lo) pair of existing fp16 buffers to write into instead of fresh ones."""
     L = _lib.load()
@@ -74,7 +74,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     w = w.contiguous()
     n = w.shape[0]
     assert w.shape[1] == k0 + k1, (w.shape, k0, k1)
-    prec = _check_precision(precision or gemm_precision)
+    prec = _check_precision(_tl("forced") or precision or gemm_prec())
     want32 = not (half_copy == "only" or split_out == "only")
     if out is None and want32:
         out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
@@ -87,13 +87,6 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     K = k0 + k1
     use16 = prec == "f16" and K % 64 == 0 and (k1 == 0 or k0 % 64 == 0)
     x3_shape = K % 32 == 0 and (k1 == 0 or k0 % 32 == 0)
-    if use16 and lens is not None and half_copy == "no":
-        # The fp16 GEMM has no ragged mode: it would write EVERY row — and ragged callers (AdaGML committing the matching
-        # descriptors of the pairs that stop at a layer into a persistent buffer) rely on untouched rows.  Ragged calls on the
-        # fp16 path therefore run on the split-fp16 kernel (same pipe, three products, honours lens) or, for odd K, on the
-        # exact-fp32 one.
-        use16 = False
-        prec = "x3" if x3_shape else "f32"
     usex3 = prec == "x3" and x3_shape
     if half_copy != "no":
         if not use16:
@@ -128,9 +121,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                                                None, None, 0, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _p(lens), int(t_pad),
                                                _st()), "pram_linear_x3_f32")
         return out
-    if use16:
-        _lib.check(L.pram_linear_f16_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual),
-                                         n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _st()),
+    if use16:      # ragged calls included: tiles without a valid row are skipped, only valid rows are stored (as on the other paths)
+        _lib.check(L.pram_linear_f16_ragged_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(_w16(w)), _p(bias), _p(residual),
+                                                n, _p(out), n, m, n, float(alpha), flags, _p(rc), _p(rs), int(rcols), _p(lens), int(t_pad), _st()),
                    "pram_linear_f16_f32")
         return out
     _lib.check(L.pram_linear_ragged_f32(_p(x), k0, k0, _p(x2), k1, k1, _p(w), _p(bias), _p(residual),
@@ -374,52 +367,73 @@ def _check_precision(p: str) -> str:
 
 
 def set_precision(p: str) -> None:
-    """Process-wide default for both the GEMM / convolution family and the attention family."""
+    """Process-wide default for both the GEMM / convolution family and the attention family (thread-local scopes override it)."""
     global attention_precision, gemm_precision
     attention_precision = gemm_precision = _check_precision(p)
 
 
 def current_precision() -> str:
-    return attention_precision if attention_precision == gemm_precision else f"gemm {gemm_precision} / attention {attention_precision}"
+    g, a = gemm_prec(), attn_prec()
+    return a if a == g else f"gemm {g} / attention {a}"
 
 
-_forced_precision = None      # set by forced_precision(): wins over every precision_scope entered inside it
+import threading as _threading
+
+# Scopes (precision_scope / forced_precision / guard_scope) and the guard's nesting depth are PER HOST THREAD: a process that drives
+# several GPUs from one thread each must not see another thread's model-level override or nesting depth.  The module attributes
+# gemm_precision / attention_precision / x3_guard stay the process-wide DEFAULTS (what set_precision() and the environment set);
+# gemm_prec() / attn_prec() / guard_policy() return what is in force for the calling thread.
+_tls = _threading.local()
+
+
+def _tl(name, default=None):
+    return getattr(_tls, name, default)
+
+
+def gemm_prec() -> str:
+    """MFMA path of the token GEMMs / convolutions in force for the calling thread (scope override, else the process default)."""
+    return _tl("forced") or _tl("gemm") or gemm_precision
+
+
+def attn_prec() -> str:
+    """MFMA path of the attention family in force for the calling thread."""
+    return _tl("forced") or _tl("attn") or attention_precision
+
+
+def guard_policy() -> str:
+    return _tl("guard") or x3_guard
 
 
 class forced_precision:
-    """``with ops.forced_precision("f32"): ...`` — every op and every model inside runs on that MFMA path, whatever the
-    models' own ``.precision`` says (the range guard's fallback run)."""
+    """``with ops.forced_precision("f32"): ...`` — every op and every model this thread runs inside the block uses that MFMA
+    path, whatever the models' own ``.precision`` says (the range guard's fallback run)."""
 
     def __init__(self, p: str):
         self.p = _check_precision(p)
 
     def __enter__(self):
-        global _forced_precision, attention_precision, gemm_precision
-        self.saved = (_forced_precision, attention_precision, gemm_precision)
-        _forced_precision = attention_precision = gemm_precision = self.p
+        self.saved = _tl("forced")
+        _tls.forced = self.p
 
     def __exit__(self, *exc):
-        global _forced_precision, attention_precision, gemm_precision
-        _forced_precision, attention_precision, gemm_precision = self.saved
+        _tls.forced = self.saved
         return False
 
 
 class precision_scope:
-    """``with ops.precision_scope("x3"): ...`` — what a model with a ``.precision`` attribute wraps its forward in."""
+    """``with ops.precision_scope("x3"): ...`` — what a model with a ``.precision`` attribute wraps its forward in (None: no
+    override).  Thread-local; an enclosing forced_precision wins."""
 
     def __init__(self, p: Optional[str]):
-        self.p = p
+        self.p = None if p is None else _check_precision(p)
 
     def __enter__(self):
-        global attention_precision, gemm_precision
-        self.saved = (attention_precision, gemm_precision)
-        p = _forced_precision or self.p      # the range guard's re-run overrides per-model settings too
-        if p is not None:
-            attention_precision = gemm_precision = _check_precision(p)
+        self.saved = (_tl("gemm"), _tl("attn"))
+        if self.p is not None:
+            _tls.gemm = _tls.attn = self.p
 
     def __exit__(self, *exc):
-        global attention_precision, gemm_precision
-        attention_precision, gemm_precision = self.saved
+        _tls.gemm, _tls.attn = self.saved
         return False
 
 
@@ -430,15 +444,45 @@ class precision_scope:
 #     launch and, when it is set, re-run the call on the exact-fp32 kernels (x3_guard = "fallback", the default), raise
 #     (x3_guard = "raise"), or leave it to the caller (x3_guard = "deferred": no synchronisation; ask x3_range_exceeded());
 #   * pipeline.QueryPipeline does the same once per run; bench.py defers it to the end of the timed region and reports it.
+# WHETHER there is anything to read is decided by what was launched, not by the precision settings: every binding that launches a
+# splitting kernel marks its device (_mark_x3: all of them fetch their weight planes through split_weight), so a model that runs
+# x3 under its own .precision inside an f32 process, or the x3 kernels the fp16 path uses on purpose (GML's matching descriptors),
+# arm the guard all the same — and a pure f32 / f16 run never synchronises for it.
 x3_guard = _os.environ.get("PRAM_X3_GUARD", "fallback")
 X3_GUARDS = ("fallback", "raise", "deferred")
 _status_words = {}
-_guard_depth = 0
+_x3_pending = set()       # device indices with split-fp16 launches since their status word was last read
+_x3_counts = {}           # device index -> split-fp16 launches so far (x3_launch_count: what a hipGraph capture compares)
+
+
+def _dev_index(device) -> int:
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def _mark_x3(device) -> None:
+    i = _dev_index(device)
+    _x3_pending.add(i)
+    _x3_counts[i] = _x3_counts.get(i, 0) + 1
+
+
+def x3_launch_count(device=None) -> int:
+    """Split-fp16 launches issued (or captured) on ``device`` so far: a caller that replays captured work compares the count
+    around the capture to know whether its replays can set the status word."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return _x3_counts.get(_dev_index(device), 0)
+
+
+def x3_launched(device=None) -> bool:
+    """True if a split-fp16 kernel was launched on ``device`` since its status word was last read (no synchronisation)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return _dev_index(device) in _x3_pending
 
 
 def _x3_status(device) -> torch.Tensor:
     """The status word of ``device`` (allocated and registered with the library on first use)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = _dev_index(device)
     w = _status_words.get(key)
     if w is None:
         with torch.cuda.device(key):
@@ -455,6 +499,7 @@ def x3_range_exceeded(device=None, reset: bool = True) -> bool:
         device = torch.device("cuda", torch.cuda.current_device())
     w = _x3_status(device)
     torch.cuda.synchronize(device)
+    _x3_pending.discard(_dev_index(device))      # everything launched so far has reported
     hit = bool(int(w[0].item()) & 1)
     if hit and reset:
         w.zero_()
@@ -462,7 +507,7 @@ def x3_range_exceeded(device=None, reset: bool = True) -> bool:
 
 
 class guard_scope:
-    """``with ops.guard_scope("deferred"): ...`` — the range-guard policy of the enclosed model calls."""
+    """``with ops.guard_scope("deferred"): ...`` — the range-guard policy of the model calls this thread makes inside."""
 
     def __init__(self, mode: str):
         if mode not in X3_GUARDS:
@@ -470,41 +515,40 @@ class guard_scope:
         self.mode = mode
 
     def __enter__(self):
-        global x3_guard
-        self.saved, x3_guard = x3_guard, self.mode
+        self.saved = _tl("guard")
+        _tls.guard = self.mode
 
     def __exit__(self, *exc):
-        global x3_guard
-        x3_guard = self.saved
+        _tls.guard = self.saved
         return False
 
 
 def guarded_call(fn, device):
-    """Run ``fn()`` (a model entry point) under the range guard: only the OUTERMOST guarded call checks the status word, after
-    its last launch; nothing is checked while a stream is capturing (a hipGraph cannot synchronise: GraphedPipeline checks after
-    the replay) or when neither matrix family runs on the split path."""
-    global _guard_depth
-    outer = _guard_depth == 0
-    _guard_depth += 1
+    """Run ``fn()`` (a model entry point) under the range guard: only the OUTERMOST guarded call of a thread checks the status
+    word, after its last launch, and only if a split-fp16 kernel was launched on the device since the word was last read; nothing
+    is checked while a stream is capturing (a hipGraph cannot synchronise: GraphedPipeline checks after the replay)."""
+    depth = _tl("depth", 0)
+    _tls.depth = depth + 1
     try:
         out = fn()
     finally:
-        _guard_depth -= 1
-    if not outer or x3_guard == "deferred" or "x3" not in (gemm_precision, attention_precision):
+        _tls.depth = depth
+    policy = guard_policy()
+    if depth != 0 or policy == "deferred" or not x3_launched(device):
         return out
-    if x3_guard not in X3_GUARDS:
-        raise _lib.PramHipError(f"unknown x3 guard {x3_guard!r} (expected one of {X3_GUARDS})")
+    if policy not in X3_GUARDS:
+        raise _lib.PramHipError(f"unknown x3 guard {policy!r} (expected one of {X3_GUARDS})")
     if torch.cuda.is_current_stream_capturing() or not x3_range_exceeded(device):
         return out
-    if x3_guard == "raise":
+    if policy == "raise":
         raise _lib.PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 (fp16(16 x) overflows) — re-run with "
                                 "precision 'f32' (or PRAM_X3_GUARD=fallback)")
-    _guard_depth += 1
+    _tls.depth = depth + 1
     try:
         with forced_precision("f32"):
             return fn()
     finally:
-        _guard_depth -= 1
+        _tls.depth = depth
 
 
 # Derived forms of a (static) weight tensor — its fp16 copy, its split planes — live exactly as long as the tensor object
@@ -542,7 +586,8 @@ def split_weight(w: torch.Tensor):
         hi = ts.half()
         lo = (ts - hi.float()).half()
         return hi.contiguous(), lo.contiguous(), float(scale)
-    _x3_status(w.device)      # every split-fp16 GEMM / convolution comes through here: the range guard's status word is registered
+    _x3_status(w.device)      # every split-fp16 GEMM / convolution comes through here: the range guard's status word is registered,
+    _mark_x3(w.device)        # and the device is marked as having something to report (guarded_call / x3_launched)
     return _derived(w, "x3", make)
 
 
@@ -572,7 +617,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    prec = _check_precision(precision or attention_precision)
+    prec = _check_precision(_tl("forced") or precision or attn_prec())
     if prec == "x3":
         prec = "f32"      # fp32 operands in HBM: the split path starts at the projection (attention_x3 takes its planes)
     if prec == "f32":
@@ -749,7 +794,7 @@ def attention_cross(qk: torch.Tensor, v: torch.Tensor, pairs: int, heads: int, t
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    prec = _check_precision(precision or attention_precision)
+    prec = _check_precision(_tl("forced") or precision or attn_prec())
     if prec == "x3":
         prec = "f32"
     if prec == "f32":
@@ -935,7 +980,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=N
     pad = ks // 2
     Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
     out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    prec = _check_precision(precision or gemm_precision)
+    prec = _check_precision(_tl("forced") or precision or gemm_prec())
     if prec == "x3" and Cin % 32 == 0:
         wh, wl, ws = split_weight(w)
         _lib.check(L.pram_conv2d_nhwc_x3_f32(_p(x), B, H, W, Cin, _p(wh), _p(wl), ws, _p(bias), _p(scale), _p(shift), _p(residual),

@@ -192,12 +192,16 @@ class GraphedPipeline:
                     self._run_eager()
             torch.cuda.current_stream(images.device).wait_stream(side)
             torch.cuda.synchronize(images.device)
+            n0 = ops.x3_launch_count(images.device)
             if not self.split:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     self.out = self._run_eager()
             else:
                 self._capture_split()
+            # whether a replay can set the range guard's status word is a property of what was CAPTURED (per-model precisions
+            # included), not of the process-wide precision settings
+            self.uses_x3 = ops.x3_launch_count(images.device) > n0
 
     def _capture_split(self):
         pipe, images = self.pipe, self.images
@@ -269,10 +273,19 @@ class GraphedPipeline:
                 self.ref[k].copy_(v)
         self._replay()
         guard = self.pipe.guard
-        if guard != "deferred" and "x3" in (ops.gemm_precision, ops.attention_precision) and ops.x3_range_exceeded(images.device):
+        if guard != "deferred" and self.uses_x3 and ops.x3_range_exceeded(images.device):
             if guard == "raise":
                 from ._lib import PramHipError
                 raise PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 in the replayed step")
+            # The captured buffers (self.out, self.record) now hold the overflowed replay: the result of THIS call is the eager
+            # exact-fp32 re-run returned below, and self.record follows it (fresh tensors, not the captured ones) so that a caller
+            # reading g.record after run() never sees the NaN-derived record.  The re-run cannot overflow (no split kernels under
+            # forced_precision), hence "deferred".  One status word serves the whole device: a caller that keeps OTHER replays in
+            # flight on other streams must use replay() and check ops.x3_range_exceeded() itself once they are done — the reset
+            # here is not ordered against them.
             with ops.forced_precision("f32"):
-                return self.pipe.run(images, ref, self.stages, guard="deferred")
+                out = self.pipe.run(images, ref, self.stages, guard="deferred")
+                if self.with_record:
+                    self.record = QueryPipeline.pack_record(out)
+            return out
         return self.out

@@ -342,8 +342,11 @@ def test_ragged_linear_on_the_fp16_path_leaves_other_rows_untouched(dev):
     ops.linear(x, w, out=out, lens=lens, t_pad=128, precision="f16")
     assert float((out[128:256] - 7).abs().max()) == 0.0 and float((out[384:] - 7).abs().max()) == 0.0
     assert float((out[256 + 37:384] - 7).abs().max()) == 0.0
+    # the fp16 GEMM itself since round 4 (it used to detour through the split kernels): the dense fp16 result, bit for bit
+    dense = ops.linear(x, w, precision="f16")
+    assert torch.equal(out[:128], dense[:128]) and torch.equal(out[256:256 + 37], dense[256:256 + 37])
     want = x.double() @ w.double().t()
-    assert float((out[:128].double() - want[:128]).abs().max()) < 1e-4 and float((out[256:256 + 37].double() - want[256:256 + 37]).abs().max()) < 1e-4
+    assert float((out[:128].double() - want[:128]).abs().max()) < 5e-3
 
 
 # ------------------------------------------------------------------------------------------------ MLP tail as a GEMM pair

@@ -1,0 +1,174 @@
+"""GPU (MI355X): round-4 additions — ragged fp16 GEMM, the range guard armed by launches (per-model precision inside an f32 process,
+the split kernels the fp16 path uses on purpose), the record of a graph replay that fell back, zero-filled ragged heads."""
+import pytest
+import torch
+
+from pram_amd import ops, weights as W
+from pram_amd._lib import PramHipError
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_ragged_fp16_gemm_stores_valid_rows_only_and_stays_on_the_fp16_kernel(dev):
+    """linear(precision='f16', lens=...) runs the fp16 GEMM itself (no detour through the split kernels: nothing to report to the
+    range guard), equals the dense fp16 result on the valid rows bit for bit and leaves every other row of `out` untouched."""
+    T, S, K, N = 192, 5, 256, 320
+    x = W.normal(21, "r4/x", (S * T, K), 1.0).to(dev)
+    x2 = W.normal(21, "r4/x2", (S * T, K), 1.0).to(dev)
+    w = W.normal(21, "r4/w", (N, 2 * K), 0.05).to(dev)
+    b = W.normal(21, "r4/b", (N,), 0.1).to(dev)
+    res = W.normal(21, "r4/r", (S * T, N), 1.0).to(dev)
+    lens = torch.tensor([192, 0, 77, 128, 1], dtype=torch.int32, device=dev)
+    ops.x3_range_exceeded(dev)
+    dense = ops.linear(x, w, b, x2=x2, residual=res, alpha=0.5, precision="f16")
+    out = torch.full((S * T, N), -7.0, device=dev)
+    got = ops.linear(x, w, b, x2=x2, residual=res, alpha=0.5, precision="f16", lens=lens, t_pad=T, out=out)
+    assert got.data_ptr() == out.data_ptr() and not ops.x3_launched(dev)
+    valid = (torch.arange(T, device=dev)[None] < lens[:, None]).reshape(-1)
+    assert torch.equal(got[valid], dense[valid])
+    assert bool((got[~valid] == -7.0).all())
+    # narrow output (the 128-row tile) and a value past the split format's range: fine on this path (fp16 holds 65504)
+    wn = W.normal(21, "r4/wn", (48, K), 0.05).to(dev)
+    xb = x.clone()
+    xb[3, 3] = 5000.0
+    outn = torch.full((S * T, 48), 3.0, device=dev)
+    gn = ops.linear(xb, wn, precision="f16", lens=lens, t_pad=T, out=outn)
+    dn = ops.linear(xb, wn, precision="f16")
+    assert torch.equal(gn[valid], dn[valid]) and bool((gn[~valid] == 3.0).all()) and bool(torch.isfinite(gn[valid]).all())
+    assert not ops.x3_launched(dev)
+
+
+def _hot_segnet(dev, gain, n_class=113):
+    from pram_amd.nets.load_segnet import load_segnet
+    sd = dict(H.segnet_sd())
+    sd["input_proj.weight"] = sd["input_proj.weight"] * gain
+    sd["input_proj.bias"] = sd["input_proj.bias"] * gain
+    m = load_segnet('segnetvit', n_class, 256, 15, 1024)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def _tokens(dev, N, seed=31):
+    desc = W.normal(seed, "r4/d", (1, N, 256), 0.05).to(dev)
+    kp = torch.stack([torch.floor(W.uniform(seed, "r4/kx", (N,), 4.0, 636.0)), torch.floor(W.uniform(seed, "r4/ky", (N,), 4.0, 476.0))], -1)[None].to(dev)
+    return {"seg_descriptors": desc, "keypoints": kp, "image": torch.empty(1, 3, 480, 640)}
+
+
+def test_guard_sees_a_models_own_split_precision_inside_an_f32_process(dev):
+    """Process default f32 (or f16), model.set_precision('x3'), residual stream beyond the split format's range: the outermost
+    guarded call — the pipeline's, outside the model's precision scope — must still notice and fall back."""
+    from pram_amd.nets.sfd2 import ResNet4x
+    from pram_amd.pipeline import GraphedPipeline, QueryPipeline
+    net, _ = _hot_segnet(dev, 6.0e3)
+    data = _tokens(dev, 192)
+    old = ops.gemm_precision, ops.attention_precision
+    for base in ("f32", "f16"):
+        ops.gemm_precision = ops.attention_precision = base
+        try:
+            ops.x3_range_exceeded(dev)
+            want = net.set_precision("f32")(data)["prediction"]
+            assert not ops.x3_launched(dev)                         # an exact-fp32 forward has nothing to report
+            net.set_precision("x3")
+            with ops.guard_scope("raise"):
+                with pytest.raises(PramHipError):
+                    net(data)
+            got = net(data)["prediction"]                           # default policy: fallback
+            assert torch.equal(got, want) and bool(torch.isfinite(got).all())
+            # ... and through the pipeline, whose guarded call is the outermost one and sits outside every model's scope
+            sfd2 = ResNet4x()
+            sfd2.load_state_dict(H.sfd2_sd(), strict=True)
+            sfd2 = sfd2.to(dev).eval().set_precision("f32")
+            pipe = QueryPipeline(sfd2, net, None, max_keypoints=128, min_keypoints=8)
+            img = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)]).to(dev)
+            out = pipe.run(img, None, stages="er")
+            n = int(out["counts"][0])
+            assert bool(torch.isfinite(out["prediction"][0, :n]).all())
+            with pytest.raises(PramHipError):
+                pipe.run(img, None, stages="er", guard="raise")
+            g = GraphedPipeline(pipe, img, None, stages="er", record=True)
+            assert g.uses_x3
+            ops.x3_range_exceeded(dev)
+            res = g.run(img)
+            assert bool(torch.isfinite(res["prediction"][0, :n]).all()) and torch.equal(res["prediction"], out["prediction"])
+            # the record a caller reads after run() is the fallback's, not the overflowed replay's
+            assert g.record is not None and bool(torch.isfinite(g.record[0, :n]).all())
+            assert torch.equal(g.record, QueryPipeline.pack_record(out))
+        finally:
+            net.set_precision(None)
+            ops.gemm_precision, ops.attention_precision = old
+    ops.x3_range_exceeded(dev)
+
+
+def test_fp16_path_matcher_reports_its_split_kernels_to_the_guard(dev):
+    """The fp16 path keeps GML's final descriptor projection and score matrix on the split kernels on purpose; their range is
+    checked although the process precision says 'f16' (the guard used to look at the settings only)."""
+    from pram_amd.nets.gml import GML
+    sd = dict(H.gml_sd())
+    net = GML({}).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in H.pair_data(0, 256, 256)[0].items()}
+    ops.x3_range_exceeded(dev)
+    with ops.guard_scope("deferred"):
+        net.set_precision("f16").produce_matches(data)
+    assert ops.x3_launched(dev)
+    assert not ops.x3_range_exceeded(dev)
+    ref = net.set_precision("f16").produce_matches(data)
+    # an out-projection that leaves the split format's range (the planes carry out / d^(1/4) * 16)
+    hot = dict(sd)
+    last = net.n_layers - 1
+    hot[f"out_proj.{last}.weight"] = sd[f"out_proj.{last}.weight"] * 4.0e5
+    net2 = GML({}).eval()
+    net2.load_state_dict(hot, strict=True)
+    net2 = net2.to(dev).set_precision("f16")
+    with ops.guard_scope("raise"):
+        with pytest.raises(PramHipError):
+            net2.produce_matches(data)
+    out = net2.produce_matches(data)                               # fallback: exact fp32, finite
+    assert bool(torch.isfinite(out["matching_scores0"]).all())
+    assert ref["matches0"].shape == out["matches0"].shape
+    ops.x3_range_exceeded(dev)
+
+
+def test_ragged_sc_head_is_zero_beyond_a_frames_keypoints(dev):
+    """with_sc: the 'sc' rows beyond lens read zero like 'prediction' (they used to be uninitialised memory)."""
+    from pram_amd.nets.segnetvit import SegNetViT
+    net = SegNetViT({"n_class": 113, "with_sc": True}).eval()
+    net.load_state_dict(W.make_state_dict('segnetvit', net.state_dict(), seed=7), strict=True)
+    net = net.to(dev)
+    N = 128
+    d = _tokens(dev, N)
+    data = {"seg_descriptors": d["seg_descriptors"].repeat(2, 1, 1), "keypoints": d["keypoints"].repeat(2, 1, 1), "image": torch.empty(2, 3, 480, 640),
+            "lens": torch.tensor([N, 40], dtype=torch.int32, device=dev)}
+    for prec in ("x3", "f32", "f16"):
+        torch.empty(1 << 22, device=dev).fill_(float("nan"))        # poison what the allocator hands out next
+        out = net.set_precision(prec)(data)
+        assert bool((out["sc"][1, 40:] == 0).all()) and bool((out["prediction"][1, 40:] == 0).all()), prec
+        assert bool(torch.isfinite(out["sc"]).all()) and bool(torch.isfinite(out["prediction"]).all()), prec
+        full = net({k: (v[:1] if torch.is_tensor(v) and v.shape[0] == 2 else v) for k, v in data.items() if k != "lens"})
+        assert float((out["sc"][0] - full["sc"][0]).abs().max()) < (1e-5 if prec != "f16" else 1e-1)
+    ops.x3_range_exceeded(dev)
+
+
+def test_sinkhorn_on_non_finite_scores_never_faults(dev):
+    """All-NaN (and partly NaN) score matrices: rows / columns without a comparable value are reported unmatched — the arg-max
+    sentinel used to be used as an address in the mutual check (a GPU memory fault under the deferred guard policy)."""
+    g = torch.Generator().manual_seed(5)
+    for m, n in ((300, 257), (64, 2049)):
+        d = torch.randn(2, m, (n + 3) // 4 * 4, generator=g).to(dev)      # rows padded to 16 bytes, n valid columns (as GML hands it over)
+        d[0] = float("nan")
+        d[1, 3] = float("nan")
+        d[1, :, 5] = float("inf")
+        bin_score = torch.ones(1, device=dev)
+        for dual in (False, True):
+            r = ops.sinkhorn_match(d.clone(), bin_score, 20, 0.2, dual_softmax=dual, n_valid=n)
+            torch.cuda.synchronize()
+            assert bool((r["matches0"][0] == -1).all()) and bool((r["matches1"][0] == -1).all())
+            assert int(r["matches0"][1].max()) < n and int(r["matches1"][1].max()) < m
