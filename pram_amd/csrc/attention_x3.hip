@@ -344,10 +344,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
 // NWV: waves per workgroup.  Four (128 query rows, two workgroups per CU) everywhere but on full grids of MODE 0, where eight
 // (256 rows, one workgroup per CU: the same 64 KB of LDS, the same registers per wave) stage every K / V tile once per 256 query
 // rows instead of once per 128 — the staging is what the tile loop pays for beside its MFMAs (profiles/r02_x3_attention_ablation.txt).
-// VAR: profiling variants (PRAM_ATTN_VAR, never set in production).  bit 0: the staged K / V tiles are written to LDS in the MIDDLE
-// of the tile (between the score / soft-max phase and P V) instead of at its end — both target stages are free for the whole tile;
-// bit 3: no exponentials (garbage results, the rest keeps its shape).
-template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW, int VAR = 0>
+template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW>
 __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe_kernel(ArgsX p) {
     constexpr int BQV = QW * NWV;            // query rows of the workgroup
     constexpr int SROWS = NWV * 8;           // K rows / V^T rows one staging pass of the workgroup covers (8 threads per row)
@@ -578,8 +575,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
                 const f2 y = __builtin_elementwise_fma((f2){st[t][e], st[t][e + 1]}, sc2, sh2);      // one rounding, like fmaf
-                const float p0 = (VAR & 8) ? y[0] : __builtin_amdgcn_exp2f(y[0]);       // argument <= 14
-                const float p1 = (VAR & 8) ? y[1] : __builtin_amdgcn_exp2f(y[1]);
+                const float p0 = __builtin_amdgcn_exp2f(y[0]);       // argument <= 14
+                const float p1 = __builtin_amdgcn_exp2f(y[1]);
                 const half2_t pk = {(_Float16)p0, (_Float16)p1};
                 ph[t][e >> 3][e & 7] = pk[0];
                 ph[t][e >> 3][(e & 7) + 1] = pk[1];
@@ -688,20 +685,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                 __builtin_amdgcn_sched_group_barrier(0x002, HI ? 18 : 6, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (VAR & 1) {
-                lstore_v((j + 1) & 1);
-                if (more_k) lstore_k(j & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             pv(vbuf);
-        } else if constexpr (VAR & 1) {
-            lstore_v((j + 1) & 1);
-            if (more_k) lstore_k(j & 1);
         }
-        if constexpr (!(VAR & 1)) {
-            lstore_v((j + 1) & 1);
-            if (more_k) lstore_k(j & 1);
-        }
+        lstore_v((j + 1) & 1);
+        if (more_k) lstore_k(j & 1);
         __syncthreads();
     };
     int j = t0;
@@ -1117,12 +1104,6 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
             if (units256 >= 256 && !(wv && wv[0] == '4')) {
                 p.q_tiles = cdiv(m_max, 2 * BQ);
                 const dim3 grid8(batch * heads * p.q_tiles), blk8(2 * NW * 64);
-                static const char* var = getenv("PRAM_ATTN_VAR");      // profiling variants of the eight-wave kernel
-                const int vr = var ? atoi(var) : 0;
-                if (psplit && vr == 1) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0, 2 * NW, 1>), grid8, blk8, 0, st, p);
-                else if (psplit && vr == 8) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0, 2 * NW, 8>), grid8, blk8, 0, st, p);
-                else if (psplit && vr == 9) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0, 2 * NW, 9>), grid8, blk8, 0, st, p);
-                else
                 if (psplit) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0, 2 * NW>), grid8, blk8, 0, st, p);
                 else hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 0, 2 * NW>), grid8, blk8, 0, st, p);
                 return pram_launch_status("pram_attention_x3_f32");
