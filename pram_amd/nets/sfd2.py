@@ -15,6 +15,12 @@ import torch.nn as nn
 from .. import ops
 from . import _blocks as blk
 
+import os as _os
+# conv4's ResBlocks as ONE kernel each on the split-fp16 path (pram_resblock_nhwc_x3_f32: bit-identical to the three kernels it replaces).
+# Opt-in: in its first form the fused kernel is no faster (758 vs 735 us per block at the bench shape, profiles/r04_resblock_probe.txt):
+# with one 133 KB workgroup per CU nothing overlaps its own HBM streaming (DESIGN.md 4.12 has the anatomy and what it would take).
+FUSED_RES = _os.environ.get("PRAM_FUSED_RES", "0") == "1"
+
 RGB_mean = [0.485, 0.456, 0.406]
 RGB_std = [0.229, 0.224, 0.225]
 
@@ -115,6 +121,11 @@ class ResNet4x(blk.PackedCache, nn.Module):
         o4 = o3b
         for i in range(3):
             p = f"conv4.{i}"
+            if FUSED_RES and ops.gemm_prec() == "x3" and o4.shape[-1] == 256:
+                # the whole block in one kernel: the two intermediate maps never leave the CU (bit-identical to the three ops below)
+                o4 = ops.resblock_nhwc(o4, P[p + ".w1"], P[p + ".s1"], P[p + ".t1"], P[p + ".w2"], P[p + ".s2"], P[p + ".t2"],
+                                       P[p + ".w3"], P[p + ".s3"], P[p + ".t3"])
+                continue
             y = ops.conv2d_nhwc(o4, P[p + ".w1"], None, P[p + ".s1"], P[p + ".t1"], ks=1, relu=True)
             y = ops.conv3x3_grouped_nhwc(y, P[p + ".w2"], P[p + ".s2"], P[p + ".t2"], groups=32, relu=True)
             o4 = ops.conv2d_nhwc(y, P[p + ".w3"], None, P[p + ".s3"], P[p + ".t3"], residual=o4, ks=1, relu=True)
