@@ -20,8 +20,8 @@
  * Limits (each is checked and comes back as PRAM_E_ARG with a message, never as a wrong result):
  *   - attention heads are exactly 64 wide (the shipped models: hidden 256 = 4 heads; pram_amd's Python layer raises on any
  *     other hidden_dim before it gets here);
- *   - keypoint selection keeps at most 8192 keypoints per frame when max_keypoints is positive (the top-k is sorted in LDS),
- *     or all of them (max_keypoints >= h * w);
+ *   - keypoint selection sorts a top-k of up to 8192 keypoints per frame in LDS; larger bounds sort in the caller's workspace
+ *     (pram_select_keypoints_workspace_bytes accounts for it) and max_keypoints >= h * w keeps everything unsorted;
  *   - AdaGML pruning handles token sets of at most 8192 tokens (pram_adagml_prune_f32);
  *   - LayerNorm rows are at most 1024 wide; the split-fp16 GEMMs need K % 32 == 0 (other shapes: the exact-fp32 entry);
  *   - the split-fp16 operands carry value * 16 in fp16: a finite |x| >= 4094.97 does not fit.  This one is NOT a silent limit
@@ -411,8 +411,8 @@ size_t pram_select_keypoints_workspace_bytes(int batch, int h, int w, int max_ke
  * otherwise row-major.  fallback_ref: -1 = each image tests its own count (per-query
  * semantics), >= 0 = every image uses that image's count (reference tests element 0).
  * kpts [b][max_keypoints][2] (x,y) fp32, scores [b][max_keypoints], counts [b].
- * max_keypoints is in (0, 8192] (the top-k is sorted in LDS) or >= h*w (= keep all: the reference's
- * max_keypoints < 0, nets/sfd2.py:324; row-major order, never sorted). */
+ * max_keypoints > 0: up to 8192 the top-k is sorted in LDS, beyond that in the workspace (the reference has no bound,
+ * nets/sfd2.py:38-50); >= h*w = keep all (the reference's max_keypoints < 0, nets/sfd2.py:324: row-major order, never sorted). */
 int pram_select_keypoints_f32(const float* nms, int batch, int h, int w, float conf_th,
                               int min_keypoints, int border, int max_keypoints, int fallback_ref,
                               float* kpts, float* scores, int* counts, void* workspace, void* stream);

@@ -112,6 +112,8 @@ struct SelWs {
     int* cnt_hi;            // [batch]   #(nms >= conf_th), no border test  (fallback decision)
     unsigned* cand;         // [batch][h*w]  flat indices of candidates, row-major order
     unsigned* cbits;        // [batch][h*w]  their score bit patterns (same order), so later passes stream one array
+    unsigned long long* keys;   // [batch][p2]  sort keys in global memory when max_keypoints > SEL_KMAX (p2 = next power of two); else unused
+    int p2;
 };
 
 __global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict__ nms, int hw, float th, int* __restrict__ cnt) {
@@ -156,11 +158,15 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sbuf, int* total) {
     return res;
 }
 
+// BIG: max_keypoints beyond the in-LDS sort (nets/sfd2.py:38-50 has no bound): the same selection with its sort keys in global
+// memory — a rare configuration (a frame needs more than 8192 candidates after the NMS), built for completeness, not for speed.
+template <bool BIG>
 __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restrict__ nms, int h, int w, float conf_th,
                                                            int min_kp, int border, int kmax, int fallback_ref, SelWs ws,
                                                            float* __restrict__ kpts, float* __restrict__ scores,
                                                            int* __restrict__ counts) {
-    __shared__ unsigned long long keys[SEL_KMAX];
+    __shared__ unsigned long long lds_keys[BIG ? 1 : SEL_KMAX];
+    unsigned long long* keys = BIG ? ws.keys + (size_t)blockIdx.x * ws.p2 : lds_keys;
     __shared__ int hist[256];
     __shared__ int sbuf[17];
     __shared__ unsigned s_prefix;
@@ -291,6 +297,7 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
     int p2 = 1;
     while (p2 < kmax) p2 <<= 1;
     for (int i = kmax + tid; i < p2; i += SEL_T) keys[i] = 0ull;
+    if (BIG) __threadfence_block();      // the keys live in global memory: make them visible to the workgroup at every barrier
     __syncthreads();
     // ---- bitonic sort, descending: (score desc, flat index asc)
     for (int k2 = 2; k2 <= p2; k2 <<= 1) {
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
                     if (desc ? (a < bb) : (a > bb)) { keys[i] = bb; keys[ixj] = a; }
                 }
             }
+            if (BIG) __threadfence_block();
             __syncthreads();
         }
     }
@@ -443,7 +451,7 @@ extern "C" int pram_simple_nms_f32(const float* score, float* nms, int batch, in
     return pram_launch_status("pram_simple_nms_f32");
 }
 
-static SelWs sel_carve(void* ws, int batch, int h, int w, size_t* total) {
+static SelWs sel_carve(void* ws, int batch, int h, int w, int max_keypoints, size_t* total) {
     SelWs s;
     char* base = (char*)ws;
     size_t off = 0;
@@ -453,14 +461,22 @@ static SelWs sel_carve(void* ws, int batch, int h, int w, size_t* total) {
     off += ((size_t)batch * h * w * 4 + 255) & ~(size_t)255;
     s.cbits = (unsigned*)(base + off);
     off += ((size_t)batch * h * w * 4 + 255) & ~(size_t)255;
+    s.keys = nullptr;
+    s.p2 = 0;
+    if (max_keypoints > SEL_KMAX && max_keypoints < h * w) {      // top-k beyond the in-LDS sort: keys in global memory
+        int p2 = 1;
+        while (p2 < max_keypoints) p2 <<= 1;
+        s.keys = (unsigned long long*)(base + off);
+        s.p2 = p2;
+        off += ((size_t)batch * p2 * 8 + 255) & ~(size_t)255;
+    }
     if (total) *total = off;
     return s;
 }
 
 extern "C" size_t pram_select_keypoints_workspace_bytes(int batch, int h, int w, int max_keypoints) {
     size_t total = 0;
-    sel_carve(nullptr, batch, h, w, &total);
-    (void)max_keypoints;
+    sel_carve(nullptr, batch, h, w, max_keypoints, &total);
     return total;
 }
 
@@ -468,22 +484,23 @@ extern "C" int pram_select_keypoints_f32(const float* nms, int batch, int h, int
                                          int border, int max_keypoints, int fallback_ref, float* kpts, float* scores,
                                          int* counts, void* workspace, void* stream) {
     PRAM_REQUIRE(nms && kpts && scores && counts && workspace, "pram_select_keypoints_f32: null pointer");
-    // a bound >= h*w can never be exceeded ("keep all", nets/sfd2.py:324 with max_keypoints < 0): the in-LDS top-k
-    // sort, which is what limits the bound to SEL_KMAX, is then unreachable
-    PRAM_REQUIRE((max_keypoints > 0 && max_keypoints <= SEL_KMAX) || max_keypoints >= h * w,
-                 "pram_select_keypoints_f32: max_keypoints=%d not in (0, %d] and not >= h*w (keep all)", max_keypoints, SEL_KMAX);
+    // a bound >= h*w can never be exceeded ("keep all", nets/sfd2.py:324 with max_keypoints < 0): the top-k sort is then
+    // unreachable; bounds up to SEL_KMAX sort in LDS, larger ones in the workspace (pram_select_keypoints_workspace_bytes grows)
+    PRAM_REQUIRE(max_keypoints > 0, "pram_select_keypoints_f32: max_keypoints=%d must be positive (>= h*w = keep all)", max_keypoints);
     PRAM_REQUIRE(fallback_ref < batch, "pram_select_keypoints_f32: fallback_ref out of range");
     PRAM_REQUIRE(conf_th > 0.f, "pram_select_keypoints_f32: conf_th must be positive");
     if (batch == 0) return PRAM_OK;
     hipStream_t st = (hipStream_t)stream;
-    SelWs ws = sel_carve(workspace, batch, h, w, nullptr);
+    SelWs ws = sel_carve(workspace, batch, h, w, max_keypoints, nullptr);
     if (hipMemsetAsync(ws.cnt_hi, 0, (size_t)batch * 4, st) != hipSuccess) {
         pram_set_error("pram_select_keypoints_f32: memset failed");
         return PRAM_E_LAUNCH;
     }
     hipLaunchKernelGGL(sel_count_kernel, dim3(64, batch), dim3(256), 0, st, nms, h * w, conf_th, ws.cnt_hi);
-    hipLaunchKernelGGL(sel_select_kernel, dim3(batch), dim3(SEL_T), 0, st, nms, h, w, conf_th, min_keypoints, border,
-                       max_keypoints, fallback_ref, ws, kpts, scores, counts);
+    if (ws.keys) hipLaunchKernelGGL(sel_select_kernel<true>, dim3(batch), dim3(SEL_T), 0, st, nms, h, w, conf_th, min_keypoints, border,
+                                    max_keypoints, fallback_ref, ws, kpts, scores, counts);
+    else hipLaunchKernelGGL(sel_select_kernel<false>, dim3(batch), dim3(SEL_T), 0, st, nms, h, w, conf_th, min_keypoints, border,
+                            max_keypoints, fallback_ref, ws, kpts, scores, counts);
     return pram_launch_status("pram_select_keypoints_f32");
 }
 

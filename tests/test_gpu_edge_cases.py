@@ -85,8 +85,12 @@ def test_select_keypoints_max_k_and_border_only(dev):
     kps, scs = R.select_keypoints(s, 0.005, 10, 4, 8192)
     kp, sc, cnt = ops.select_keypoints(s.to(dev).contiguous(), 0.005, 10, 4, 8192, fallback_ref=0)
     assert cnt.tolist() == [8192] and torch.equal(kp[0].cpu(), kps[0]) and torch.equal(sc[0].cpu(), scs[0])
+    # one more than the in-LDS sort holds: sorted in the workspace since round 4 (the reference has no bound), same canonical order
+    kps1, scs1 = R.select_keypoints(s, 0.005, 10, 4, 8193)
+    kp1, sc1, cnt1 = ops.select_keypoints(s.to(dev).contiguous(), 0.005, 10, 4, 8193, fallback_ref=0)
+    assert cnt1.tolist() == [8193] and torch.equal(kp1[0].cpu(), kps1[0]) and torch.equal(sc1[0].cpu(), scs1[0])
     with pytest.raises(Exception):
-        ops.select_keypoints(s.to(dev).contiguous(), 0.005, 10, 4, 8193)
+        ops.select_keypoints(s.to(dev).contiguous(), 0.005, 10, 4, 0)
     # all candidates inside the removed border -> zero keypoints
     z = torch.zeros(1, 64, 64)
     z[0, :4] = 0.5

@@ -227,3 +227,22 @@ def test_sfd2_backbone_with_fused_resblocks_is_bit_identical(dev):
     finally:
         S.FUSED_RES = saved
     assert torch.equal(a, b)
+
+
+def test_select_keypoints_beyond_the_in_lds_sort(dev):
+    """max_keypoints > 8192 (the reference's top_k_keypoints has no bound, nets/sfd2.py:38-50): the top-k is sorted in the workspace
+    instead of LDS — same canonical order, bit for bit against the oracle; ties at the cut-off and the fewer-than-k case included."""
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(17)
+    Hh, Ww = 200, 256
+    nms = torch.rand(2, Hh, Ww, generator=g) * 0.9 + 0.05
+    nms[0].view(-1)[::3] = 0.0                                   # ~34 k candidates in frame 0 ...
+    nms[1].view(-1)[::2] = 0.0                                   # ... ~25 k in frame 1
+    nms[1, 50:60, 50:150] = 0.4321                               # a plateau of equal scores across the cut-off
+    for k in (10000, 16384, 20000, 40000):
+        kp, sc, cnt = ops.select_keypoints(nms.to(dev), 0.005, 128, 4, k, fallback_ref=-1)
+        okp, osc = R.select_keypoints(nms, 0.005, 128, 4, k, per_image_fallback=True)
+        for b in range(2):
+            n = int(cnt[b])
+            assert n == len(osc[b]) == min(k, n), (k, b, n, len(osc[b]))
+            assert torch.equal(sc[b, :n].cpu(), osc[b]) and torch.equal(kp[b, :n].cpu(), okp[b]), (k, b)
