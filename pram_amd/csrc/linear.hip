@@ -308,6 +308,29 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                     if (c1ok) { oh[(size_t)row * p.ldo16 + c1] = h1; ol[(size_t)row * p.ldo16 + c1] = (_Float16)(s1 - (float)h1); }
                 }
             }
+        } else if (p.out16 && stage) {
+            // plain fp16 copy through LDS, like the split planes above: a lane owns single columns of 16 rows, so direct stores are
+            // 2-byte scatters; each wave transposes its 32 x 64 block in 4.5 KB of the (idle) staging memory and writes 16 bytes per lane
+            typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+            constexpr int LD = 72;
+            _Float16* sh = stage + wave * (32 * LD);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = acc_row(0, e, h);
+                sh[rr * LD + r] = (_Float16)q0[e];
+                sh[rr * LD + 32 + r] = (_Float16)q1[e];
+            }
+            _Float16* o16 = reinterpret_cast<_Float16*>(p.out16);
+            const int seg = lane & 7;
+            const bool cok = cbase + seg * 8 < p.n;                 // n % 8 == 0 on this path
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = (lane >> 3) + 8 * j;
+                const int row = rbase + mi * 32 + rr;
+                const half8v v = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
+                if (cok && row < p.m) *reinterpret_cast<half8v*>(o16 + (size_t)row * p.ldo16 + cbase + seg * 8) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         } else if (p.out16) {
             _Float16* o16 = reinterpret_cast<_Float16*>(p.out16);
 #pragma unroll
@@ -444,7 +467,9 @@ __global__ __launch_bounds__(gemm16::NT, 2) void linear_f16_kernel(LinArgs p, co
     } else {
         mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, acc);
     }
-    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN);
+    // fp16 outputs (q / k, the hidden layer, ...) leave as whole 16-byte row segments through the now idle staging memory
+    _Float16* stage = (p.out16 && !p.out16_lo && p.n % 8 == 0 && p.ldo16 % 8 == 0) ? reinterpret_cast<_Float16*>(&smem) : nullptr;
+    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN, stage);
 }
 
 // split-fp16 variant (gemm_core_x3.h): wh / wl = the weight matrix * w_scale split into two fp16 planes [n][K] on the
