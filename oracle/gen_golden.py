@@ -85,7 +85,8 @@ def save(name, **arrs):
 
 def gen_segnetvit(ref):
     print("SegNetViT")
-    for tag, (B, N, C) in {"b2_n512_c113": (2, 512, 113), "b1_n300_c161": (1, 300, 161)}.items():
+    # c513 = BASELINE C5's class count (configs/config_train_aachen_sfd2.yaml); N kept small: the fixture pins the head width
+    for tag, (B, N, C) in {"b2_n512_c113": (2, 512, 113), "b1_n300_c161": (1, 300, 161), "b1_n640_c513": (1, 640, 513)}.items():
         model = ref["load"].load_segnet("segnetvit", C, 256, 15, 1024).eval()
         sd = W.make_state_dict("segnetvit", model.state_dict(), seed=7)
         model.load_state_dict(sd, strict=True)
@@ -173,7 +174,9 @@ def gen_gml(ref):
     net = g.GML({}).eval()
     sd = W.make_state_dict("gml", net.state_dict(), seed=7)
     net.load_state_dict(sd, strict=True)
-    for tag, (m, n, key) in {"m384_n512": (384, 512, "image_shape"), "m256_n256_img": (256, 256, "image")}.items():
+    # m512_n1024 = SURVEY 8(d)'s secondary shape (a query's voted keypoints against a compressed reference frame)
+    for tag, (m, n, key) in {"m384_n512": (384, 512, "image_shape"), "m256_n256_img": (256, 256, "image"),
+                             "m512_n1024": (512, 1024, "image_shape")}.items():
         data, gt = _pair_data(0, m, n, key)
         with torch.no_grad():
             r_def = net(data)
@@ -218,7 +221,7 @@ def gen_adagml(ref):
     net = a.AdaGML({}).eval()
     sd = W.make_state_dict("adagml", net.state_dict(), seed=7)
     net.load_state_dict(sd, strict=True)
-    for tag, (m, n, pidx) in {"m640_n768": (640, 768, 1), "m300_n280": (300, 280, 2)}.items():
+    for tag, (m, n, pidx) in {"m640_n768": (640, 768, 1), "m300_n280": (300, 280, 2), "m512_n1024": (512, 1024, 3)}.items():
         data, gt = _pair_data(pidx, m, n)
         with torch.no_grad():
             r = net.produce_matches(data, p=0.0)

@@ -33,7 +33,7 @@ def _tokens(B, N):
     return torch.stack([t[0] for t in toks]), torch.stack([t[1] for t in toks])
 
 
-@pytest.mark.parametrize("tag", ["b2_n512_c113", "b1_n300_c161"])
+@pytest.mark.parametrize("tag", ["b2_n512_c113", "b1_n300_c161", "b1_n640_c513"])
 def test_segnetvit_golden(dev, golden, tag):
     g = golden(f"segnetvit_{tag}")
     B, N, C = int(g["B"]), int(g["N"]), int(g["C"])
@@ -184,7 +184,7 @@ def _gml(dev):
     return g.to(dev).eval()
 
 
-@pytest.mark.parametrize("tag,key", [("m384_n512", "image_shape"), ("m256_n256_img", "image")])
+@pytest.mark.parametrize("tag,key", [("m384_n512", "image_shape"), ("m256_n256_img", "image"), ("m512_n1024", "image_shape")])
 def test_gml_golden(dev, golden, tag, key):
     g = golden(f"gml_{tag}")
     data, _ = H.pair_data(0, int(g["m"]), int(g["n"]), key, device=dev)
@@ -245,7 +245,7 @@ def _adagml(dev):
     return a.to(dev).eval()
 
 
-@pytest.mark.parametrize("tag", ["m640_n768", "m300_n280"])
+@pytest.mark.parametrize("tag", ["m640_n768", "m300_n280", "m512_n1024"])
 def test_adagml_golden(dev, golden, tag):
     g = golden(f"adagml_{tag}")
     data, _ = H.pair_data(int(g["pair_index"]), int(g["m"]), int(g["n"]), device=dev)

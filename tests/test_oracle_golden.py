@@ -57,7 +57,7 @@ def test_argmax_first_occurrence():
 
 
 def test_segnetvit_golden(golden):
-    for tag in ("b2_n512_c113", "b1_n300_c161"):
+    for tag in ("b2_n512_c113", "b1_n300_c161", "b1_n640_c513"):
         g = golden(f"segnetvit_{tag}")
         B, N, C = int(g["B"]), int(g["N"]), int(g["C"])
         sd = H.segnet_sd(C)
@@ -84,7 +84,7 @@ def test_segnetvit_with_sc_golden(golden):
 
 
 def test_gml_golden(golden):
-    for tag, key in (("m384_n512", "image_shape"), ("m256_n256_img", "image")):
+    for tag, key in (("m384_n512", "image_shape"), ("m256_n256_img", "image"), ("m512_n1024", "image_shape")):
         g = golden(f"gml_{tag}")
         data, _ = H.pair_data(0, int(g["m"]), int(g["n"]), key)
         r = R.gml_produce_matches(H.gml_sd(), data, p=0.2)
@@ -95,7 +95,7 @@ def test_gml_golden(golden):
 
 
 def test_adagml_golden(golden):
-    for tag in ("m640_n768", "m300_n280"):
+    for tag in ("m640_n768", "m300_n280", "m512_n1024"):
         g = golden(f"adagml_{tag}")
         data, _ = H.pair_data(int(g["pair_index"]), int(g["m"]), int(g["n"]))
         probes = {}
