@@ -92,3 +92,29 @@ def test_round4_entry_points_declared_bound_and_exported():
         assert re.search(r"\b" + n + r"\s*\(", header), n
         assert n in _lib._SIGS, n
         assert getattr(lib, n) is not None
+
+
+def test_every_entry_point_survives_null_arguments():
+    """The C ABI validates before it touches anything: every exported entry called with NULL pointers and zero sizes returns an
+    error code (or, for the size / query helpers, a harmless value) — never a crash — and the launching ones leave a message in
+    pram_last_error.  Run in a child process so that a regression is a failed assertion, not a dead test session."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from pram_amd import _lib
+L = _lib.load()
+helpers = {"pram_hip_version", "pram_last_error", "pram_fill_u32", "pram_linear_x3_ssq_parts", "pram_attention_x3_is_split",
+           "pram_attention_x3_mfma_per_tile", "pram_attention_x3_set_chunk_keys", "pram_attention_x3_set_p_split",
+           "pram_attention_x3_set_split_target"}
+for name, (res, args) in sorted(_lib._SIGS.items()):
+    vals = [None if a is _lib.P else (0.0 if a is _lib.F else 0) for a in args]
+    r = getattr(L, name)(*vals)
+    if name in helpers or name.endswith("_workspace_bytes"):
+        continue
+    assert isinstance(r, int) and r < 0, (name, r)
+    assert L.pram_last_error(), name
+print("ok", len(_lib._SIGS))
+""" % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
