@@ -108,30 +108,112 @@ static void nms_launch(const float* score, float* out, float* ws, int batch, int
 constexpr int SEL_T = 1024;       // threads per image
 constexpr int SEL_KMAX = 8192;    // max_keypoints supported by the in-LDS sort
 
+constexpr int SEL_SLABS = 64;     // pixel slabs per frame of the count / compaction kernels (one workgroup each)
+
 struct SelWs {
     int* cnt_hi;            // [batch]   #(nms >= conf_th), no border test  (fallback decision)
+    int* slab;              // [batch][SEL_SLABS][2]  candidates per slab inside the border: >= conf_th | >= conf_th / 2
     unsigned* cand;         // [batch][h*w]  flat indices of candidates, row-major order
     unsigned* cbits;        // [batch][h*w]  their score bit patterns (same order), so later passes stream one array
     unsigned long long* keys;   // [batch][p2]  sort keys in global memory when max_keypoints > SEL_KMAX (p2 = next power of two); else unused
     int p2;
 };
 
-__global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict__ nms, int hw, float th, int* __restrict__ cnt) {
-    const int b = blockIdx.y;
+// slab s of a frame = pixels [s * slab_px, (s + 1) * slab_px) (slab_px a multiple of 8).  One workgroup per (slab, frame):
+// the frame's count above conf_th without the border test (the min_keypoints fallback decision, nets/sfd2.py:311) and, inside
+// the border, the slab's candidates at conf_th and at conf_th / 2 — whichever threshold the frame ends up with, the compaction
+// kernel below knows every slab's offset without a second counting pass.
+__global__ __launch_bounds__(256) void sel_count_kernel(const float* __restrict__ nms, int h, int w, int slab_px, float th, int border,
+                                                        SelWs ws) {
+    __shared__ int red[3][4];
+    const int b = blockIdx.y, sl = blockIdx.x;
+    const int hw = h * w;
     const float* img = nms + (size_t)b * hw;
-    int c = 0;
-    if ((hw & 3) == 0) {
-        const float4* img4 = reinterpret_cast<const float4*>(img);
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < (hw >> 2); i += gridDim.x * 256) {
-            const float4 v = img4[i];
-            c += (v.x >= th) + (v.y >= th) + (v.z >= th) + (v.w >= th);
-        }
-    } else {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) c += img[i] >= th;
+    const int p0 = sl * slab_px, p1 = min(hw, p0 + slab_px);
+    const float th2 = th * 0.5f;
+    int c_hi = 0, c1 = 0, c2 = 0;
+    for (int i = p0 + threadIdx.x; i < p1; i += 256) {
+        const float v = img[i];
+        const int y = i / w, x = i - y * w;
+        const bool inb = y >= border && y < h - border && x >= border && x < w - border;
+        c_hi += v >= th;
+        c1 += inb && v >= th;
+        c2 += inb && v >= th2;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[b], c);
+    for (int o = 32; o > 0; o >>= 1) { c_hi += __shfl_xor(c_hi, o, 64); c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = c_hi; red[1][wave] = c1; red[2][wave] = c2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_hi = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        if (t_hi) atomicAdd(&ws.cnt_hi[b], t_hi);      // integer: the order of the additions does not matter
+        ws.slab[((size_t)b * SEL_SLABS + sl) * 2 + 0] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        ws.slab[((size_t)b * SEL_SLABS + sl) * 2 + 1] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+}
+
+// Ordered compaction of the candidates (>= th, inside the border) by SEL_SLABS workgroups per frame: a slab's offset is the sum
+// of the counts of the slabs before it, inside the slab a block scan keeps the row-major order — the list (and everything
+// downstream) is the one the single-workgroup sweep produced, 307 200 pixels are no longer one workgroup's 38 dependent scans.
+__global__ __launch_bounds__(256) void sel_compact_kernel(const float* __restrict__ nms, int h, int w, int slab_px, float conf_th,
+                                                          int min_kp, int border, int fallback_ref, SelWs ws) {
+    __shared__ int wsum[4];
+    __shared__ int s_base;
+    const int b = blockIdx.y, sl = blockIdx.x;
+    const int hw = h * w;
+    const float* img = nms + (size_t)b * hw;
+    const int ref = fallback_ref < 0 ? b : fallback_ref;
+    const bool low = ws.cnt_hi[ref] <= min_kp;
+    const float th = low ? conf_th * 0.5f : conf_th;
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int q = 0; q < sl; ++q) off += ws.slab[((size_t)b * SEL_SLABS + q) * 2 + (low ? 1 : 0)];
+        s_base = off;
+    }
+    __syncthreads();
+    int base = s_base;
+    unsigned* cand = ws.cand + (size_t)b * hw;
+    unsigned* cbits = ws.cbits + (size_t)b * hw;
+    const int p0 = sl * slab_px, p1 = min(hw, p0 + slab_px);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PER = 8;
+    for (int sweep = p0; sweep < p1; sweep += 256 * PER) {
+        const int i0 = sweep + threadIdx.x * PER;
+        float v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = (i0 + j < p1) ? img[i0 + j] : -1.f;
+        int y = i0 / w, x = i0 - y * w;
+        unsigned keepmask = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool keep = (i0 + j < p1) && v[j] >= th && y >= border && y < h - border && x >= border && x < w - border;
+            keepmask |= (keep ? 1u : 0u) << j;
+            if (++x == w) { x = 0; ++y; }
+        }
+        const int n = __popc(keepmask);
+        int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int pre = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { if (q < wave) pre += wsum[q]; tot += wsum[q]; }
+        int pos = base + pre + inc - n;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (keepmask & (1u << j)) {
+                cand[pos] = (unsigned)(i0 + j);
+                cbits[pos] = __float_as_uint(v[j]);
+                ++pos;
+            }
+        base += tot;
+        __syncthreads();
+    }
 }
 
 // block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns the exclusive
@@ -174,55 +256,16 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int hw = h * w;
-    const float* img = nms + (size_t)b * hw;
     unsigned* cand = ws.cand + (size_t)b * hw;
     unsigned* cbits = ws.cbits + (size_t)b * hw;
     const int ref = fallback_ref < 0 ? b : fallback_ref;
-    const float th = (ws.cnt_hi[ref] <= min_kp) ? conf_th * 0.5f : conf_th;
 
-    // ---- pass 1: ordered compaction of the candidates (>= th, inside the border).  A thread owns 8 consecutive
-    // pixels per sweep (two float4 loads; the next sweep's loads are in flight during the block scan), so one image
-    // is 38 scans instead of 300 — the kernel is a single workgroup and every scan costs a load latency + 3 barriers.
-    constexpr int PER = 8;
-    auto load8 = [&](int base, float (&v)[PER]) {
-        const int i0 = base + tid * PER;
-        if (i0 + PER <= hw && (hw & 3) == 0) {
-            const float4 a = *reinterpret_cast<const float4*>(img + i0), bb = *reinterpret_cast<const float4*>(img + i0 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < PER; ++j) v[j] = (i0 + j < hw) ? img[i0 + j] : -1.f;
-        }
-    };
+    // ---- pass 1 ran as sel_compact_kernel: cand / cbits hold the frame's candidates in row-major order, c of them
     int c = 0;
-    float cur[PER], nxt[PER];
-    load8(0, cur);
-    for (int base = 0; base < hw; base += SEL_T * PER) {
-        if (base + SEL_T * PER < hw) load8(base + SEL_T * PER, nxt);
-        const int i0 = base + tid * PER;
-        int y = i0 / w, x = i0 - y * w;
-        unsigned keepmask = 0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const bool keep = (i0 + j < hw) && cur[j] >= th && y >= border && y < h - border && x >= border && x < w - border;
-            keepmask |= (keep ? 1u : 0u) << j;
-            if (++x == w) { x = 0; ++y; }
-        }
-        int tot;
-        int pos = c + block_excl_scan(__popc(keepmask), sbuf, &tot);
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            if (keepmask & (1u << j)) {
-                cand[pos] = (unsigned)(i0 + j);
-                cbits[pos] = __float_as_uint(cur[j]);
-                ++pos;
-            }
-        c += tot;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) cur[j] = nxt[j];
+    {
+        const bool low = ws.cnt_hi[ref] <= min_kp;
+        for (int q = 0; q < SEL_SLABS; ++q) c += ws.slab[((size_t)b * SEL_SLABS + q) * 2 + (low ? 1 : 0)];
     }
-    __threadfence_block();
-    __syncthreads();
 
     float* ko = kpts + (size_t)b * kmax * 2;
     float* so = scores + (size_t)b * kmax;
@@ -457,6 +500,8 @@ static SelWs sel_carve(void* ws, int batch, int h, int w, int max_keypoints, siz
     size_t off = 0;
     s.cnt_hi = (int*)(base + off);
     off += ((size_t)batch * 4 + 255) & ~(size_t)255;
+    s.slab = (int*)(base + off);
+    off += ((size_t)batch * SEL_SLABS * 2 * 4 + 255) & ~(size_t)255;
     s.cand = (unsigned*)(base + off);
     off += ((size_t)batch * h * w * 4 + 255) & ~(size_t)255;
     s.cbits = (unsigned*)(base + off);
@@ -496,7 +541,10 @@ extern "C" int pram_select_keypoints_f32(const float* nms, int batch, int h, int
         pram_set_error("pram_select_keypoints_f32: memset failed");
         return PRAM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(sel_count_kernel, dim3(64, batch), dim3(256), 0, st, nms, h * w, conf_th, ws.cnt_hi);
+    const int slab_px = (cdiv(h * w, SEL_SLABS) + 7) & ~7;
+    hipLaunchKernelGGL(sel_count_kernel, dim3(SEL_SLABS, batch), dim3(256), 0, st, nms, h, w, slab_px, conf_th, border, ws);
+    hipLaunchKernelGGL(sel_compact_kernel, dim3(SEL_SLABS, batch), dim3(256), 0, st, nms, h, w, slab_px, conf_th, min_keypoints, border,
+                       fallback_ref, ws);
     if (ws.keys) hipLaunchKernelGGL(sel_select_kernel<true>, dim3(batch), dim3(SEL_T), 0, st, nms, h, w, conf_th, min_keypoints, border,
                                     max_keypoints, fallback_ref, ws, kpts, scores, counts);
     else hipLaunchKernelGGL(sel_select_kernel<false>, dim3(batch), dim3(SEL_T), 0, st, nms, h, w, conf_th, min_keypoints, border,
