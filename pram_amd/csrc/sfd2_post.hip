@@ -297,15 +297,37 @@ __global__ __launch_bounds__(SEL_T) void sel_select_kernel(const float* __restri
                 if (i0 + u * SEL_T < c && (bits[u] & himask) == prefix) atomicAdd(&hist[(bits[u] >> shift) & 255], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int rem = s_remaining;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (hist[d] >= rem) break;
-                rem -= hist[d];
+        // the digit of the k-th largest: the largest d whose suffix count S(d) = #(digit >= d) reaches the remaining rank.  The
+        // 256 suffix counts come from one parallel scan (thread t < 256 owns digit 255 - t: a prefix scan in descending digit
+        // order) — the serial walk over the bins by one thread was 256 dependent LDS reads per pass, four passes per frame.
+        {
+            const int rem = s_remaining;
+            __syncthreads();                                   // everyone has read s_remaining / s_prefix before they change
+            int own = 0, inc = 0;
+            if (tid < 256) {
+                own = hist[255 - tid];
+                inc = own;
+                const int lane = tid & 63;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t2 = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t2;
+                }
+                if (lane == 63) sbuf[tid >> 6] = inc;
             }
-            s_remaining = rem;
-            s_prefix = prefix | ((unsigned)d << shift);
+            __syncthreads();
+            if (tid < 256) {
+                int pre = 0;
+                for (int q = 0; q < (tid >> 6); ++q) pre += sbuf[q];
+                const int s_incl = pre + inc, s_excl = s_incl - own;      // #(digit >= d), #(digit > d) for d = 255 - tid
+                // exactly one digit satisfies S(d + 1) < rem <= S(d); if the candidates run out first (cannot happen: c > kmax
+                // here) digit 0 takes what is left, as the serial walk did
+                const bool hit = (s_excl < rem && rem <= s_incl) || (tid == 255 && s_incl < rem);
+                if (hit) {
+                    s_remaining = rem - s_excl;
+                    s_prefix = prefix | ((unsigned)(255 - tid) << shift);
+                }
+            }
         }
         __syncthreads();
     }
