@@ -20,6 +20,8 @@ import os as _os
 # Opt-in: in its first form the fused kernel is no faster (758 vs 735 us per block at the bench shape, profiles/r04_resblock_probe.txt):
 # with one 133 KB workgroup per CU nothing overlaps its own HBM streaming (DESIGN.md 4.12 has the anatomy and what it would take).
 FUSED_RES = _os.environ.get("PRAM_FUSED_RES", "0") == "1"
+# conv1a -> conv1b as one kernel on the split-fp16 path (pram_sfd2_conv1_x3_f32); 0: two kernels (conv1a on the exact-fp32 MFMA kernel)
+FUSED_CONV1 = _os.environ.get("PRAM_FUSED_CONV1", "1") != "0"
 
 RGB_mean = [0.485, 0.456, 0.406]
 RGB_std = [0.229, 0.224, 0.225]
@@ -115,7 +117,12 @@ class ResNet4x(blk.PackedCache, nn.Module):
         def cbr(x, n, stride=1):
             return ops.conv2d_nhwc(x, P[n + ".w"], P[n + ".b"], P[n + ".s"], P[n + ".t"], ks=3, stride=stride, relu=True)
 
-        o1b = cbr(cbr(x, "conv1a"), "conv1b", 2)
+        if FUSED_CONV1 and ops.gemm_prec() == "x3":
+            # conv1a -> conv1b in one launch: the 480 x 640 x 64 map between them never goes to HBM
+            o1b = ops.sfd2_conv1(x, P["conv1a.w"], P["conv1a.b"], P["conv1a.s"], P["conv1a.t"],
+                                 P["conv1b.w"], P["conv1b.b"], P["conv1b.s"], P["conv1b.t"])
+        else:
+            o1b = cbr(cbr(x, "conv1a"), "conv1b", 2)
         o2b = cbr(cbr(o1b, "conv2a"), "conv2b", 2)
         o3b = cbr(cbr(o2b, "conv3a"), "conv3b")
         o4 = o3b

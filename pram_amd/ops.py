@@ -575,17 +575,21 @@ def _w16(w: torch.Tensor) -> torch.Tensor:
     return _derived(w, "h16", lambda t: t.half().contiguous())
 
 
+def split_weight_raw(t: torch.Tensor):
+    """(hi, lo, scale) of a tensor, uncached: see split_weight."""
+    import math
+    amax = float(t.abs().max())
+    scale = 2.0 ** math.floor(math.log2(16384.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+    ts = t.float() * scale
+    hi = ts.half()
+    lo = (ts - hi.float()).half()
+    return hi.contiguous(), lo.contiguous(), float(scale)
+
+
 def split_weight(w: torch.Tensor):
     """-> (hi, lo, scale): w * scale = hi + lo as two fp16 tensors of w's shape; scale = the power of two that puts
     max|w| into [2^13, 2^14) (exact to apply and to undo), so hi + lo carries 22 bits of every weight above 2^-17 max|w|."""
-    def make(t):
-        amax = float(t.abs().max())
-        import math
-        scale = 2.0 ** math.floor(math.log2(16384.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
-        ts = t.float() * scale
-        hi = ts.half()
-        lo = (ts - hi.float()).half()
-        return hi.contiguous(), lo.contiguous(), float(scale)
+    make = split_weight_raw
     _x3_status(w.device)      # every split-fp16 GEMM / convolution comes through here: the range guard's status word is registered,
     _mark_x3(w.device)        # and the device is marked as having something to report (guarded_call / x3_launched)
     return _derived(w, "x3", make)
@@ -1017,6 +1021,27 @@ def resblock_nhwc(x: torch.Tensor, w1: torch.Tensor, s1, t1, w2: torch.Tensor, s
     w3h, w3l, ws3 = split_weight(w3)
     _lib.check(L.pram_resblock_nhwc_x3_f32(_p(x), B, H, W, _p(w1h), _p(w1l), ws1, _p(s1), _p(t1), _p(w2), _p(s2), _p(t2),
                                            _p(w3h), _p(w3l), ws3, _p(s3), _p(t3), _p(out), _st()), "pram_resblock_nhwc_x3_f32")
+    return out
+
+
+def sfd2_conv1(x4: torch.Tensor, wa: torch.Tensor, ba, sa, ta, wb: torch.Tensor, bb, sb, tb) -> torch.Tensor:
+    """SFD2's conv1a -> conv1b (3x3 / stride 1 / 3 -> 64, then 3x3 / stride 2 / 64 -> 64, each bias -> BN -> ReLU; nets/sfd2.py:135-139,
+    281-282) in ONE launch on the split-fp16 path (pram_sfd2_conv1_x3_f32): the 1.26 GB conv1a map never exists.  x4: the NHWC4 image
+    (image_to_nhwc4); wa [64, 3, 3, 4], wb [64, 3, 3, 64] as conv2d_nhwc takes them.  -> [B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64]."""
+    L = _lib.load()
+    assert x4.is_contiguous() and x4.shape[-1] == 4 and tuple(wa.shape) == (64, 3, 3, 4) and tuple(wb.shape) == (64, 3, 3, 64)
+    B, H, W, _ = x4.shape
+
+    def pad48(t):      # [64][36] -> [64][48]: K padded to three 16-deep steps, then the usual split
+        flat = t.reshape(64, 36).float()
+        return split_weight_raw(torch.cat([flat, flat.new_zeros(64, 12)], 1).contiguous())
+    _x3_status(x4.device)
+    _mark_x3(x4.device)
+    wah, wal, wsa = _derived(wa, "x3pad48", pad48)
+    wbh, wbl, wsb = split_weight(wb)
+    out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=x4.device, dtype=torch.float32)
+    _lib.check(L.pram_sfd2_conv1_x3_f32(_p(x4), B, H, W, _p(wah), _p(wal), wsa, _p(ba), _p(sa), _p(ta), _p(wbh), _p(wbl), wsb,
+                                        _p(bb), _p(sb), _p(tb), _p(out), _st()), "pram_sfd2_conv1_x3_f32")
     return out
 
 

@@ -246,3 +246,37 @@ def test_select_keypoints_beyond_the_in_lds_sort(dev):
             n = int(cnt[b])
             assert n == len(osc[b]) == min(k, n), (k, b, n, len(osc[b]))
             assert torch.equal(sc[b, :n].cpu(), osc[b]) and torch.equal(kp[b, :n].cpu(), okp[b]), (k, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 128), (1, 33, 47), (1, 16, 32), (1, 5, 7), (2, 480, 640)])
+def test_fused_conv1(dev, shape):
+    """pram_sfd2_conv1_x3_f32 = conv1a -> conv1b (bias, BN, ReLU each; stride 2 on the second): against an fp64 reference of both
+    layers (fp32-class), and against the two-kernel path (whose conv1a is the exact-fp32 MFMA kernel: agreement to rounding, not
+    bit for bit); even / odd frame sizes, frames smaller than a tile, the bench's 480 x 640; range guard on an out-of-range pixel."""
+    B, Hh, Ww = shape
+    F = torch.nn.functional
+    wa = W.normal(5, "c1/wa", (64, 3, 3, 4), 0.25)
+    wa[..., 3] = 0.0                                               # the NHWC4 image's fourth channel does not exist
+    wb = W.normal(5, "c1/wb", (64, 3, 3, 64), 0.06)
+    par = {k: (W.uniform(5, "c1/" + k, (64,), 0.6, 1.4) if k[0] == "s" else W.normal(5, "c1/" + k, (64,), 0.2)) for k in ("ba", "sa", "ta", "bb", "sb", "tb")}
+    img = W.normal(6, f"c1/img{shape}", (B, 3, Hh, Ww), 1.0)
+    x4 = ops.image_to_nhwc4(img.to(dev))
+    d = {k: v.to(dev) for k, v in par.items()}
+    ops.x3_range_exceeded(dev)
+    got = ops.sfd2_conv1(x4, wa.to(dev), d["ba"], d["sa"], d["ta"], wb.to(dev), d["bb"], d["sb"], d["tb"])
+    assert not ops.x3_range_exceeded(dev)
+    y = ops.conv2d_nhwc(x4, wa.to(dev), d["ba"], d["sa"], d["ta"], ks=3, stride=1, relu=True)
+    two = ops.conv2d_nhwc(y, wb.to(dev), d["bb"], d["sb"], d["tb"], ks=3, stride=2, relu=True, precision="x3")
+    bn = lambda v, s, t: v * par[s].double().view(1, -1, 1, 1) + par[t].double().view(1, -1, 1, 1)
+    r = torch.relu(bn(F.conv2d(img.double(), wa[..., :3].double().permute(0, 3, 1, 2), par["ba"].double(), padding=1), "sa", "ta"))
+    r = torch.relu(bn(F.conv2d(r, wb.double().permute(0, 3, 1, 2), par["bb"].double(), stride=2, padding=1), "sb", "tb")).permute(0, 2, 3, 1)
+    assert tuple(got.shape) == tuple(two.shape) == tuple(r.shape)
+    scale = float(r.abs().max())
+    e_f, e_2 = float((got.double().cpu() - r).abs().max()), float((two.double().cpu() - r).abs().max())
+    assert e_f <= max(2.0 * e_2, 2e-6 * scale), (e_f, e_2, scale)
+    assert float((got - two).abs().max()) <= 4e-6 * scale
+    if shape == (2, 96, 128):
+        bad = img.clone()
+        bad[1, 2, 40, 50] = 5.0e3
+        ops.sfd2_conv1(ops.image_to_nhwc4(bad.to(dev)), wa.to(dev), d["ba"], d["sa"], d["ta"], wb.to(dev), d["bb"], d["sb"], d["tb"])
+        assert ops.x3_range_exceeded(dev)
