@@ -378,6 +378,23 @@ int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int 
                                   const float* scale, const float* shift, float* out, int groups,
                                   int relu, void* stream);
 
+/* pram_conv2d_nhwc_x3_f32 whose result leaves as the split operand of the next split-fp16 layer instead of fp32: out_hi =
+ * fp16(16 y), out_lo = fp16(16 y - out_hi), [batch][ho][wo][cout] each — the same four bytes per value, and the consumer needs
+ * neither registers nor vector instructions to stage it (LDS-DMA).  cin % 32 == 0, cout even; |y| >= 4095 is reported through the
+ * range guard (status word).  Used between a ResBlock's first 1x1 and its grouped 3x3. */
+int pram_conv2d_nhwc_x3_planes(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,
+                               float w_scale, const float* bias, const float* scale, const float* shift, const float* residual,
+                               void* out_hi, void* out_lo, int cout, int ks, int stride, int relu, void* stream);
+
+/* The grouped 3x3 (8 channels per group) on the split-fp16 path: a block-diagonal product on the matrix pipe (a 32-channel block
+ * is four groups; a 16-deep k-step carries one tap of two groups), the input taken as the planes above, windows double-buffered in
+ * LDS by DMA under the MFMAs of a persistent workgroup per CU, weights in registers — the vector-ALU kernel above is bound by the
+ * LDS broadcasts of its weights.  w_hi / w_lo: the [c][3][3][8] weights * w_scale as fp16 planes; c % 64 == 0.  fp32-class (three
+ * fp16 products, fp32 accumulation): ~3e-7 relative from pram_conv3x3_grouped_nhwc_f32. */
+int pram_conv3x3_grouped_planes_x3_f32(const void* in_hi, const void* in_lo, int batch, int h, int w, int c, const void* w_hi,
+                                       const void* w_lo, float w_scale, const float* scale, const float* shift, float* out,
+                                       int groups, int relu, void* stream);
+
 /* SFD2's first two convolutions (nets/sfd2.py:135-139,281-282: conv1a 3 -> 64 3x3 stride 1, conv1b 64 -> 64 3x3 stride 2, each bias
  * -> BN -> ReLU) in ONE launch on the split-fp16 path: the 480 x 640 x 64 map between them (1.26 GB for 16 frames: the largest
  * round trip of the step) never exists — a workgroup computes the (2 * 8 + 1) x (2 * 16 + 1) window of conv1a outputs it needs

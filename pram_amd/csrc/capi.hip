@@ -23,6 +23,18 @@ unsigned int* pram_status_ptr(void) {
     return g_status[dev];
 }
 
+// compute units of the current device (persistent kernels size their grids with it); 256 when the query fails
+int pram_cu_count(void) {
+    static int g_cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (g_cus[dev] == 0) {
+        int n = 0;
+        g_cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return g_cus[dev];
+}
+
 extern "C" int pram_set_status_word(unsigned int* device_word) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {

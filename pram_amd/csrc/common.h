@@ -30,6 +30,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // The caller-owned status word of the current device (pram_set_status_word), or nullptr.
 unsigned int* pram_status_ptr(void);
+// compute units of the current device (grid size of the persistent kernels)
+int pram_cu_count(void);
 
 // Range guard of the split-fp16 path: a kernel that turns fp32 values into fp16(value * scale) parts tracks the largest
 // |value * scale| it met; 65520 and above round to +-inf in fp16 (a finite result would be garbage, usually NaN), which is

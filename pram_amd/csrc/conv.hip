@@ -22,6 +22,7 @@ struct ConvArgs {
     int ho, wo, m, k;
     int tiles_m, tiles_n;
     unsigned int* status;      // range guard of the split-fp16 path (common.h), or nullptr
+    _Float16* out_hi; _Float16* out_lo;      // PLANES epilogue: the output * 16 as two fp16 planes (the next layer's split operand)
 };
 
 // Shared epilogue of the fp32 and fp16 main loops: bias -> BN scale/shift -> residual -> ReLU.
@@ -72,6 +73,64 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
             }
         }
     }
+}
+
+// The epilogue of a layer whose result is the split operand of the next split-fp16 layer: instead of fp32 it leaves as fp16 planes
+// hi = fp16(16 v), lo = fp16(16 v - hi), [m][cout] each — what that layer's staging would compute, done once here, and the same
+// four bytes per value.  bias -> BN scale/shift -> residual -> ReLU as conv_epilogue, with the 16 folded into the constants (a
+// power of two: the same bits).  Lane pairs (two neighbouring channels of one pixel) trade halves through a DPP move so that
+// every lane still writes four bytes: even lanes two channels of the hi plane, odd lanes the same two channels of the lo plane.
+// Needs an even cout.  The largest |16 v| goes to the range guard.
+template <int MI, int WN>
+__device__ __forceinline__ void conv_epilogue_planes(const ConvArgs& p, f32x16 (&acc)[MI][2], int row0, int col0, int BM, int BN) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int nlast = p.cout - 1, mlast = p.m - 1;
+    const int rbase = row0 + wm * 32 * MI;
+    const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.cout);
+    const bool odd = lane & 1;
+    unsigned int* plane = reinterpret_cast<unsigned int*>(odd ? p.out_lo : p.out_hi);
+    // bytes of (other : mine): even lanes keep their own low half (hi_r) and take the partner's (hi_r+1); odd lanes take the
+    // partner's high half (lo_r-1) and keep their own (lo_r)
+    const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
+    const unsigned int hc = (unsigned int)p.cout >> 1;      // a row of a plane in 4-byte words
+    const bool relu = p.relu;
+    float amax = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = col0 + wn * 64 + ni * 32 + r;
+        const int cc = min(col, nlast);
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        const float sc = (p.scale ? p.scale[cc] : 1.f) * gemmx3::ACT_SCALE;
+        const float sh = (p.scale ? p.shift[cc] : 0.f) * gemmx3::ACT_SCALE;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int rb = rbase + 32 * mi + 4 * h;
+            float q[16];
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    q[e] = p.residual[(size_t)min(rb + (e & 3) + 8 * (e >> 2), mlast) * p.cout + cc] * gemmx3::ACT_SCALE;
+            }
+            unsigned int* dst = plane + (size_t)rb * hc + ((unsigned int)(col & ~1) >> 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float x = (acc[mi][ni][e] + bi) * sc + sh;
+                if (p.residual) x += q[e];
+                if (relu) x = fmaxf(x, 0.f);
+                amax = fmaxf(amax, fabsf(x));
+                const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+                const unsigned int mine = (unsigned int)__builtin_bit_cast(unsigned short, hi) | ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+                const unsigned int other = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+                const unsigned int pair = __builtin_amdgcn_perm(other, mine, sel);
+                const int ro = (e & 3) + 8 * (e >> 2);
+                if (full || (rb + ro < p.m && col < p.cout)) dst[(size_t)ro * hc] = pair;
+            }
+        }
+    }
+    x3_range_flag(p.status, amax);
 }
 
 template <bool CIN4, int MI, int WN, int BKT>
@@ -275,7 +334,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
 // wide-tile split-fp16 convolution (gemm_core_x3w.h): 256 output pixels x 256 channels per 512-thread workgroup — the 256-channel
 // layers (conv3a / conv3b / convDa.* / convPa.* / conv4 1x1: 80 % of the stack's MACs).  Same arithmetic and accumulation order
 // as conv_x3_kernel: bit-identical results.
-template <int MI, int WM, int WN>
+template <int MI, int WM, int WN, bool PLANES = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, const _Float16* __restrict__ wh,
                                                                     const _Float16* __restrict__ wl, float inv) {
     using namespace gemmx3w;
@@ -345,7 +404,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
-    conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
+    if constexpr (PLANES) conv_epilogue_planes<MI, WN>(p, acc, row0, col0, BM, BN);
+    else conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 
 // ---------------------------------------------------------------- 3x3 / stride 1 with the input window resident in LDS
@@ -807,6 +867,43 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
     return pram_launch_status("pram_conv2d_nhwc_x3_f32");
 }
 
+/* pram_conv2d_nhwc_x3_f32 with the result as the split operand of the next split-fp16 layer: out_hi = fp16(16 y),
+   out_lo = fp16(16 y - out_hi), [batch][ho][wo][cout] each (pram_conv3x3_grouped_planes_x3_f32 takes them).  cin % 32 == 0, even cout;
+   |y| >= 4095 is reported through the range guard. */
+extern "C" int pram_conv2d_nhwc_x3_planes(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,
+                                          float w_scale, const float* bias, const float* scale, const float* shift,
+                                          const float* residual, void* out_hi, void* out_lo, int cout, int ks, int stride, int relu,
+                                          void* stream) {
+    PRAM_REQUIRE(in && wgt_hi && wgt_lo && out_hi && out_lo, "pram_conv2d_nhwc_x3_planes: null pointer");
+    PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_x3_planes: ks must be 1 or 3");
+    PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_x3_planes: stride must be 1 or 2");
+    PRAM_REQUIRE(cin % 32 == 0 && w_scale > 0.f, "pram_conv2d_nhwc_x3_planes: cin=%d must be a multiple of 32", cin);
+    PRAM_REQUIRE(cout > 0 && cout % 2 == 0, "pram_conv2d_nhwc_x3_planes: cout=%d must be even", cout);
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_x3_planes: scale and shift go together");
+    if (batch == 0) return PRAM_OK;
+    const int pad = ks / 2;
+    ConvArgs p{in, nullptr, bias, scale, shift, residual, nullptr, batch, h, w, cin, cout, ks, stride, relu};
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    p.m = batch * p.ho * p.wo;
+    p.k = ks * ks * cin;
+    p.status = pram_status_ptr();
+    p.out_hi = (_Float16*)out_hi;
+    p.out_lo = (_Float16*)out_lo;
+    using CW = gemmx3w::Cfg<4, 2, 4>;
+    const size_t shm = sizeof(gemmx3w::Smem<4, 2, 4>);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_x3w_kernel<4, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set = true;
+    }
+    p.tiles_m = cdiv(p.m, CW::BM);
+    p.tiles_n = cdiv(cout, CW::BN);
+    hipLaunchKernelGGL((conv_x3w_kernel<4, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(CW::NT), shm, (hipStream_t)stream, p,
+                       (const _Float16*)wgt_hi, (const _Float16*)wgt_lo, 1.0f / (gemmx3::ACT_SCALE * w_scale));
+    return pram_launch_status("pram_conv2d_nhwc_x3_planes");
+}
+
 extern "C" int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int c, const float* wgt,
                                              const float* scale, const float* shift, float* out, int groups, int relu,
                                              void* stream) {
@@ -833,4 +930,239 @@ extern "C" int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(h * w, 32), cdiv(c, 32), batch), dim3(256), 0, (hipStream_t)stream, in,
                        out, h * w, c);
     return pram_launch_status("pram_nhwc_to_nchw_f32");
+}
+
+// ---------------------------------------------------------------- grouped 3x3 on the matrix pipe (split-fp16 path)
+// gconv3x3_kernel above is bound by the LDS broadcasts of its wave-uniform weights (16 ds_read_b128 per tap for 64 packed FMAs):
+// 237-268 us for 16 frames of 120 x 160 x 256 where its 630 MB need 140 us.  Here the grouped convolution is a block-diagonal
+// split-fp16 product: a 32-channel block is four groups, a 16-deep k-step is one tap of two groups (8 input channels each), so a
+// lane's weight operand is its group's eight weights when the step carries its group and zeros otherwise — three quarters of the
+// multiplied operand are zeros, and it is still cheap: 54 MFMAs per wave for 32 pixels x 32 channels.
+//
+// The input arrives already split (the fp16 planes pram_conv2d_nhwc_x3_planes writes: same bytes as fp32), so a window goes from
+// HBM to LDS by DMA, no register and no vector instruction in between, and a persistent workgroup (one per CU, 8 waves, a
+// channel quarter = 64 channels = 8 groups, walking 8 x 16-pixel tiles) keeps the next tile's window in flight under the
+// current tile's MFMAs: three window buffers of 2 x 184 pixels x 128 bytes (the 16-byte slot swizzled with the pixel through the
+// source addresses; a pixel outside the image reads a page of zeros).  The weights never touch LDS: a lane's column is one output
+// channel, its 72 weights (two planes) stay in registers for the kernel's life and a select zeroes them for the k-steps of the
+// other groups.  out[pixel][channel]: lanes are channels, a store instruction writes 128 contiguous bytes per pixel.
+// fp32-class (three fp16 products, fp32 accumulation), not the fp32 FMA chain of gconv3x3_kernel: the two agree to ~3e-7
+// relative (tests/test_gpu_round4.py::test_grouped_conv_on_the_matrix_pipe).
+namespace {
+namespace gx {
+constexpr int TH = 8, TW = 16, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;      // 180 window pixels
+constexpr int NT = 512, CQ = 64;                                                 // channels per workgroup (8 groups)
+constexpr int ROWBLKS = (HP + 7) / 8;                                            // 1-KiB DMA pieces (8 pixels x 128 B) per plane: 23
+constexpr int PLANE_B = ROWBLKS * 1024;                                          // 23 552 bytes
+constexpr int BUF_B = 2 * PLANE_B;
+constexpr int SMEM = 3 * BUF_B;                                                  // 141 312: one workgroup per CU
+constexpr int NDMA = (2 * ROWBLKS + NT / 64 - 1) / (NT / 64);                    // DMA instructions per wave and window (6)
+struct Args {
+    const _Float16* in_hi; const _Float16* in_lo; float* out; const _Float16* wh; const _Float16* wl; float inv;
+    const float* scale; const float* shift;
+    int batch, h, wd, c, relu, tiles_x, tiles_y;
+};
+}  // namespace gx
+
+__global__ __launch_bounds__(gx::NT, 1) void gconv3x3_x3_kernel(gx::Args p) {
+    using namespace gx;
+    using gemmx3::half8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gx_smem[];
+    // workgroup L keeps channel quarter q = L % nq and walks tiles L / nq, + stride, ...; the quarters of a tile are neighbours
+    // on one XCD and share the window's cache lines
+    const int nq = p.c / CQ;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int q = L % nq;
+    const int ntiles = p.batch * p.tiles_x * p.tiles_y, tstride = gridDim.x / nq;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // Addresses.  Everything a lane adds to a tile's origin is fixed for the kernel's life, so the planes and the output are
+    // addressed as raw buffers: 32-bit offset = (tile origin, uniform) + (lane constant), one vector add per window piece and
+    // one per tile for the stores, no 64-bit arithmetic in the loop; and a window pixel outside the image gets an offset past
+    // the buffer, which the hardware reads as zeros — the zero padding of the convolution.
+    const unsigned int plane_bytes = (unsigned int)p.batch * p.h * p.wd * p.c * 2u;
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.in_hi), 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.in_lo), 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(2u * plane_bytes), 0x00020000);
+    constexpr unsigned int PAST = 0x80000000u;      // (the host keeps the planes under 2 GiB)
+
+    // the tile walk: (b, oy0, ox0) stepped by tstride tiles without a division
+    struct Tile { int b, oy0, ox0; };
+    const int adv_x = (tstride % p.tiles_x) * TW, adv_rows = tstride / p.tiles_x;
+    const int adv_y = (adv_rows % p.tiles_y) * TH, adv_b = adv_rows / p.tiles_y;
+    auto next = [&](Tile t) {
+        t.ox0 += adv_x;
+        if (t.ox0 >= p.tiles_x * TW) { t.ox0 -= p.tiles_x * TW; t.oy0 += TH; }
+        t.oy0 += adv_y;
+        t.b += adv_b;
+        if (t.oy0 >= p.tiles_y * TH) { t.oy0 -= p.tiles_y * TH; ++t.b; }
+        return t;
+    };
+    auto elems = [&](const Tile& t, int dy, int dx) {      // element index of pixel (oy0 + dy, ox0 + dx), channel 0; wraps for -1
+        return (unsigned int)(((t.b * p.h + t.oy0 + dy) * p.wd + t.ox0 + dx) * p.c);
+    };
+    auto inside = [&](const Tile& t) { return t.oy0 >= 1 && t.ox0 >= 1 && t.oy0 + TH < p.h && t.ox0 + TW < p.wd; };
+
+    // this lane's part of a window: piece i = wave + 8 k of the 2 x 23 (plane, 8-pixel row block) pieces; the lane brings
+    // physical slot lane % 8 of window pixel 8 rowblk + lane / 8, i.e. logical slot (lane % 8) ^ ((pixel >> 1) & 7).  The last
+    // row block's pixels 180 .. 183 do not exist: they repeat pixel 179 into LDS rows nobody reads.
+    unsigned int woff[NDMA];
+    int hyx[NDMA];
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+        const int i = wave + (NT / 64) * k;
+        const int rowblk = i % ROWBLKS;
+        const int hp = min(8 * rowblk + (lane >> 3), HP - 1);
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        hyx[k] = (hy << 8) | hx;
+        woff[k] = (unsigned int)(((hy * p.wd + hx) * p.c + CQ * q) * 2 + (((lane & 7) ^ ((hp >> 1) & 7)) << 4));
+    }
+    auto fetch = [&](const Tile& t, int buf) {
+        const unsigned int org = elems(t, -1, -1) * 2u;
+        const bool in = inside(t);                   // workgroup-uniform: no pixel of the window needs the zero padding
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+            const int i = wave + (NT / 64) * k;      // wave-uniform
+            if (i < 2 * ROWBLKS) {
+                const int plane = i / ROWBLKS, rowblk = i - plane * ROWBLKS;
+                unsigned int off = org + woff[k];
+                if (!in) {
+                    const int iy = t.oy0 - 1 + (hyx[k] >> 8), ix = t.ox0 - 1 + (hyx[k] & 0xff);
+                    if (!((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd)) off = PAST;
+                }
+                auto* dst = (__attribute__((address_space(3))) void*)(gx_smem + buf * BUF_B + plane * PLANE_B + rowblk * 1024);
+                if (plane) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lo, dst, 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_hi, dst, 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    // wave = (32-pixel block pbk, 32-channel block nb); out[pixel][channel] += window[pixel + tap][group's 8 channels] . w
+    const int nb = wave & 1, pbk = wave >> 1;
+    const int tr = 32 * pbk + r, py = tr >> 4, px = tr & 15;             // this lane's pixel row of the A operand
+    const int gn = r >> 3;                                               // this lane's channel column of the B operand: group 4 nb + gn
+    const int ch = CQ * q + 32 * nb + r;
+    const float sci = (p.scale ? p.scale[ch] : 1.f) * p.inv, sh = p.scale ? p.shift[ch] : 0.f;
+    const half8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    // the column's weights [tap][ci 8], both planes: registers for the kernel's life.  k-step (tap, s) carries groups 2 s and
+    // 2 s + 1 of the block in the lane halves h = 0 / 1: the lane's operand is its weights when gn == 2 s + h, zeros otherwise
+    half8 wh[9], wl[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        wh[tap] = *reinterpret_cast<const half8*>(p.wh + (size_t)ch * 72 + tap * 8);
+        wl[tap] = *reinterpret_cast<const half8*>(p.wl + (size_t)ch * 72 + tap * 8);
+    }
+    const bool sel0 = gn == h, sel1 = gn == 2 + h;
+
+    // Three window buffers: tile i's MFMAs read buffer i % 3 while the windows of tiles i + 1 and i + 2 are in flight or landed.
+    // Tile i - 1's results stay in the accumulator registers until the barrier of round i is behind, and are stored in front of
+    // the DMA issue of window i + 2 — so the wait on top of a round has, in issue order, window i + 1, stores, window i + 2 in
+    // flight, and s_waitcnt vmcnt(pieces of i + 2) is enough for window i + 1 however stores and loads overtake each other:
+    // loads return in order, so at most that many operations left means no load of window i + 1 is left.
+    f32x16 g;
+    // accumulator element e is pixel (2 pbk + (e >> 3), 4 h + (e & 3) + 8 ((e >> 2) & 1)) of the tile, channel ch
+    const unsigned int soff = (unsigned int)(((2 * pbk * p.wd + 4 * h) * p.c + ch) * 4);
+    auto store = [&](const Tile& t) {      // BN -> ReLU -> store
+        const unsigned int off = elems(t, 0, 0) * 4u + soff;
+        const bool whole = t.oy0 + TH <= p.h && t.ox0 + TW <= p.wd;      // workgroup-uniform
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int dy = e >> 3, dx = (e & 3) + 8 * ((e >> 2) & 1);
+            float o = g[e] * sci + sh;
+            if (p.relu) o = fmaxf(o, 0.f);
+            const unsigned int eoff = (unsigned int)((dy * p.wd + dx) * p.c * 4);      // uniform: a scalar offset of the store
+            if (whole || (t.oy0 + 2 * pbk + dy < p.h && t.ox0 + 4 * h + dx < p.wd))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, o), rs_out, off, eoff, 0);
+        }
+    };
+    Tile c0, c1, c2, prev{0, 0, 0};
+    {
+        int t = L / nq;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        c0 = Tile{t / p.tiles_y, (t % p.tiles_y) * TH, tx * TW};
+    }
+    c1 = next(c0);
+    c2 = next(c1);
+    const int t0 = L / nq;
+    if (t0 < ntiles) fetch(c0, 0);
+    if (t0 + tstride < ntiles) fetch(c1, 1);
+    int buf = 0;
+    bool have = false;
+    for (int t = t0; t < ntiles; t += tstride) {
+        if (t + tstride < ntiles) {      // window t + tstride may stay in flight: the pieces of it this wave issued
+            if (wave < 2 * ROWBLKS - (NT / 64) * (NDMA - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                          // everyone's pieces have landed; everyone is done with buffer (buf + 2) % 3
+        if (have) store(prev);
+        if (t + 2 * tstride < ntiles) fetch(c2, buf == 0 ? 2 : buf - 1);
+        const unsigned char* yh = gx_smem + buf * BUF_B;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) g[e] = 0.f;
+        // a tap's four fragments (two k-steps x two planes) are read one tap ahead of the MFMAs that take them; in step s lane
+        // half h reads the eight input channels of group 2 s + h of its block: logical slot 4 nb + 2 s + h
+        half8 a[2][4];
+        auto rd = [&](int tap, half8 (&f)[4]) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int hp = (py + ky) * HWD + px + kx;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = hp * 128 + (((4 * nb + 2 * s + h) ^ ((hp >> 1) & 7)) << 4);
+                f[2 * s] = *reinterpret_cast<const half8*>(yh + off);
+                f[2 * s + 1] = *reinterpret_cast<const half8*>(yh + PLANE_B + off);
+            }
+        };
+        rd(0, a[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) rd(tap + 1, a[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink the reads back to their MFMAs)
+            const half8 (&f)[4] = a[tap & 1];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool mine = s ? sel1 : sel0;
+                const half8 bh = mine ? wh[tap] : zero8, bl = mine ? wl[tap] : zero8;
+                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * s + 1], bh, g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * s], bl, g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * s], bh, g, 0, 0, 0);
+            }
+        }
+        prev = c0;
+        have = true;
+        c0 = c1;
+        c1 = c2;
+        c2 = next(c2);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (have) store(prev);
+}
+}  // namespace
+
+/* The grouped 3x3 of the ResBlock (8 channels per group) on the split-fp16 path, as a block-diagonal product on the matrix pipe.
+   in_hi / in_lo: the input * 16 as fp16 planes [batch][h][w][c] (pram_conv2d_nhwc_x3_planes writes them); w_hi / w_lo: the
+   [c][3][3][8] weights * w_scale as fp16 planes; c % 64 == 0.  fp32-class results. */
+extern "C" int pram_conv3x3_grouped_planes_x3_f32(const void* in_hi, const void* in_lo, int batch, int h, int w, int c, const void* w_hi,
+                                                  const void* w_lo, float w_scale, const float* scale, const float* shift, float* out,
+                                                  int groups, int relu, void* stream) {
+    PRAM_REQUIRE(in_hi && in_lo && w_hi && w_lo && out, "pram_conv3x3_grouped_planes_x3_f32: null pointer");
+    PRAM_REQUIRE(groups > 0 && c == groups * 8 && c % gx::CQ == 0 && w_scale > 0.f, "pram_conv3x3_grouped_planes_x3_f32: needs 8 channels per group, c %% 64 == 0");
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv3x3_grouped_planes_x3_f32: scale and shift go together");
+    PRAM_REQUIRE((size_t)batch * h * w * c < ((size_t)1 << 29), "pram_conv3x3_grouped_planes_x3_f32: at most 2^29 elements (32-bit buffer offsets)");
+    if (batch == 0) return PRAM_OK;
+    gx::Args p{(const _Float16*)in_hi, (const _Float16*)in_lo, out, (const _Float16*)w_hi, (const _Float16*)w_lo,
+               1.0f / (gemmx3::ACT_SCALE * w_scale), scale, shift, batch, h, w, c, relu, cdiv(w, gx::TW), cdiv(h, gx::TH)};
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gconv3x3_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gx::SMEM);
+        attr = true;
+    }
+    const int nq = c / gx::CQ, ntiles = batch * p.tiles_x * p.tiles_y;
+    const int per_q = min(ntiles, max(1, pram_cu_count() / nq));      // one resident workgroup per CU, each a (quarter, tile walk)
+    hipLaunchKernelGGL(gconv3x3_x3_kernel, dim3(per_q * nq), dim3(gx::NT), gx::SMEM, (hipStream_t)stream, p);
+    return pram_launch_status("pram_conv3x3_grouped_planes_x3_f32");
 }

@@ -999,13 +999,49 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=N
     return out
 
 
+GROUPED_X3 = _os.environ.get("PRAM_GROUPED_X3", "1") != "0"      # split-fp16 path: the grouped 3x3 on the matrix pipe (0: vector ALU)
+
+
 def conv3x3_grouped_nhwc(x: torch.Tensor, w: torch.Tensor, scale, shift, groups: int, relu: bool) -> torch.Tensor:
+    """Grouped 3x3 (8 channels per group) of the ResBlock, exact fp32 on the vector ALU."""
     L = _lib.load()
     assert x.is_contiguous() and w.is_contiguous()
     B, H, W, Cc = x.shape
     out = torch.empty_like(x)
     _lib.check(L.pram_conv3x3_grouped_nhwc_f32(_p(x), B, H, W, Cc, _p(w), _p(scale), _p(shift), _p(out), groups, int(relu), _st()),
                "pram_conv3x3_grouped_nhwc_f32")
+    return out
+
+
+def conv2d_nhwc_planes(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=None, residual=None, ks: int = 1,
+                       stride: int = 1, relu: bool = False):
+    """conv2d_nhwc on the split-fp16 path with the result as fp16 planes (hi, lo), hi + lo = 16 y: the split operand of the next
+    split-fp16 layer (conv3x3_grouped_planes), written once by the producer instead of being recomputed by the consumer."""
+    L = _lib.load()
+    _chk(x, "x")
+    assert x.is_contiguous() and w.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    hi = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float16)
+    lo = torch.empty_like(hi)
+    wh, wl, ws = split_weight(w)
+    _lib.check(L.pram_conv2d_nhwc_x3_planes(_p(x), B, H, W, Cin, _p(wh), _p(wl), ws, _p(bias), _p(scale), _p(shift), _p(residual),
+                                            _p(hi), _p(lo), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_x3_planes")
+    return hi, lo
+
+
+def conv3x3_grouped_planes(hi: torch.Tensor, lo: torch.Tensor, w: torch.Tensor, scale, shift, groups: int, relu: bool) -> torch.Tensor:
+    """Grouped 3x3 (8 channels per group) on the matrix pipe (pram_conv3x3_grouped_planes_x3_f32): (hi, lo) from
+    conv2d_nhwc_planes, w [C, 3, 3, 8] fp32; fp32 NHWC result."""
+    L = _lib.load()
+    assert hi.is_contiguous() and lo.is_contiguous() and w.is_contiguous() and hi.dtype == lo.dtype == torch.float16
+    B, H, W, Cc = hi.shape
+    out = torch.empty(B, H, W, Cc, device=hi.device, dtype=torch.float32)
+    wh, wl, ws = split_weight(w)
+    _lib.check(L.pram_conv3x3_grouped_planes_x3_f32(_p(hi), _p(lo), B, H, W, Cc, _p(wh), _p(wl), ws, _p(scale), _p(shift), _p(out),
+                                                    groups, int(relu), _st()), "pram_conv3x3_grouped_planes_x3_f32")
     return out
 
 

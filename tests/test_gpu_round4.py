@@ -218,15 +218,19 @@ def test_sfd2_backbone_with_fused_resblocks_is_bit_identical(dev):
     net.load_state_dict(H.sfd2_sd(), strict=True)
     net = net.to(dev).eval()
     img = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)]).to(dev)
-    saved = S.FUSED_RES
+    saved, saved_g = S.FUSED_RES, ops.GROUPED_X3
     try:
         S.FUSED_RES = True
         a = net._backbone(img)[-1]
         S.FUSED_RES = False
+        ops.GROUPED_X3 = False      # the fused block carries the exact-fp32 grouped 3x3 of the vector kernel
         b = net._backbone(img)[-1]
+        ops.GROUPED_X3 = True       # the default: 1x1 -> planes -> grouped 3x3 on the matrix pipe (fp32-class, not the same bits)
+        c = net._backbone(img)[-1]
     finally:
-        S.FUSED_RES = saved
+        S.FUSED_RES, ops.GROUPED_X3 = saved, saved_g
     assert torch.equal(a, b)
+    assert float((c - b).abs().max()) <= 4e-6 * float(b.abs().max())
 
 
 def test_select_keypoints_beyond_the_in_lds_sort(dev):
@@ -279,4 +283,61 @@ def test_fused_conv1(dev, shape):
         bad = img.clone()
         bad[1, 2, 40, 50] = 5.0e3
         ops.sfd2_conv1(ops.image_to_nhwc4(bad.to(dev)), wa.to(dev), d["ba"], d["sa"], d["ta"], wb.to(dev), d["bb"], d["sb"], d["tb"])
+        assert ops.x3_range_exceeded(dev)
+
+
+def _planes(x):
+    """the split operand of a tensor as the kernels compute it: hi = fp16(16 x), lo = fp16(16 x - hi)"""
+    x16 = x.float() * 16.0
+    hi = x16.half()
+    return hi, (x16 - hi.float()).half()
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 32, 256), (1, 13, 21, 64), (1, 3, 5, 128), (3, 40, 48, 256), (16, 120, 160, 256)])
+@pytest.mark.parametrize("bn_relu", [True, False])
+def test_grouped_conv_on_the_matrix_pipe(dev, shape, bn_relu):
+    """pram_conv3x3_grouped_planes_x3_f32 (block-diagonal split-fp16 product from fp16 planes, windows by LDS-DMA) against the
+    exact-fp32 vector kernel and an fp64 reference of the grouped convolution: fp32-class; ragged tiles, frames smaller than a
+    tile, more tiles than resident workgroups take (the persistent walk and its double buffer), the bench's 16 x 120 x 160 x 256."""
+    B, Hh, Ww, C = shape
+    G = C // 8
+    w = W.normal(7, f"gx/w{C}", (C, 3, 3, 8), 0.12)
+    x = W.normal(8, f"gx/x{shape}", (B, Hh, Ww, C), 1.0)
+    sc = W.uniform(7, f"gx/s{C}", (C,), 0.6, 1.4).to(dev) if bn_relu else None
+    sh = W.normal(7, f"gx/t{C}", (C,), 0.2).to(dev) if bn_relu else None
+    xd, wd = x.to(dev), w.to(dev)
+    hi, lo = _planes(xd)
+    got = ops.conv3x3_grouped_planes(hi, lo, wd, sc, sh, G, bn_relu)
+    valu = ops.conv3x3_grouped_nhwc(xd, wd, sc, sh, G, bn_relu)
+    if B * Hh * Ww <= 8192:
+        r = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1, groups=G)
+        if bn_relu:
+            r = torch.relu(r * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1))
+        r = r.permute(0, 2, 3, 1)
+        scale = float(r.abs().max())
+        e_x, e_v = float((got.double().cpu() - r).abs().max()), float((valu.double().cpu() - r).abs().max())
+        assert e_x <= max(2.0 * e_v, 2e-6 * scale), (e_x, e_v, scale)
+    scale = float(valu.abs().max())
+    assert float((got - valu).abs().max()) <= 4e-6 * scale
+    again = ops.conv3x3_grouped_planes(hi, lo, wd, sc, sh, G, bn_relu)
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 32, 256, 256), (1, 7, 9, 64, 128), (1, 30, 40, 256, 64)])
+def test_conv_writes_the_next_layers_split_operand(dev, shape):
+    """pram_conv2d_nhwc_x3_planes = pram_conv2d_nhwc_x3_f32 with the split of the consumer's staging applied in the epilogue:
+    the planes are bit for bit the split of the fp32 kernel's result; the range guard trips when 16 y leaves fp16."""
+    B, Hh, Ww, Cin, Cout = shape
+    w = W.normal(9, f"pl/w{shape}", (Cout, 1, 1, Cin), 0.08)
+    x = W.normal(9, f"pl/x{shape}", (B, Hh, Ww, Cin), 1.0)
+    sc, sh = W.uniform(9, f"pl/s{Cout}", (Cout,), 0.6, 1.4).to(dev), W.normal(9, f"pl/t{Cout}", (Cout,), 0.2).to(dev)
+    xd, wd = x.to(dev), w.to(dev)
+    ops.x3_range_exceeded(dev)
+    hi, lo = ops.conv2d_nhwc_planes(xd, wd, None, sc, sh, ks=1, relu=True)
+    assert not ops.x3_range_exceeded(dev)
+    y = ops.conv2d_nhwc(xd, wd, None, sc, sh, ks=1, relu=True, precision="x3")
+    eh, el = _planes(y)
+    assert torch.equal(hi, eh) and torch.equal(lo, el)
+    if Cout == 256:
+        ops.conv2d_nhwc_planes(xd, wd, None, sc * 4000.0, sh, ks=1, relu=True)
         assert ops.x3_range_exceeded(dev)
