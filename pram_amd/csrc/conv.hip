@@ -942,7 +942,7 @@ extern "C" int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int
 // The input arrives already split (the fp16 planes pram_conv2d_nhwc_x3_planes writes: same bytes as fp32), so a window goes from
 // HBM to LDS by DMA, no register and no vector instruction in between, and a persistent workgroup (one per CU, 8 waves, a
 // channel quarter = 64 channels = 8 groups, walking 8 x 16-pixel tiles) keeps the next tile's window in flight under the
-// current tile's MFMAs: three window buffers of 2 x 184 pixels x 128 bytes (the 16-byte slot swizzled with the pixel through the
+// current tile's MFMAs: three window buffers of 2 x 184 pixels x 128 bytes (the 16-byte slot swizzled with the window column through the
 // source addresses; a pixel outside the image reads a page of zeros).  The weights never touch LDS: a lane's column is one output
 // channel, its 72 weights (two planes) stay in registers for the kernel's life and a select zeroes them for the k-steps of the
 // other groups.  out[pixel][channel]: lanes are channels, a store instruction writes 128 contiguous bytes per pixel.
@@ -1006,7 +1006,9 @@ __global__ __launch_bounds__(gx::NT, 1) void gconv3x3_x3_kernel(gx::Args p) {
     auto inside = [&](const Tile& t) { return t.oy0 >= 1 && t.ox0 >= 1 && t.oy0 + TH < p.h && t.ox0 + TW < p.wd; };
 
     // this lane's part of a window: piece i = wave + 8 k of the 2 x 23 (plane, 8-pixel row block) pieces; the lane brings
-    // physical slot lane % 8 of window pixel 8 rowblk + lane / 8, i.e. logical slot (lane % 8) ^ ((pixel >> 1) & 7).  The last
+    // physical slot lane % 8 of window pixel 8 rowblk + lane / 8 = (hy, hx), i.e. logical slot (lane % 8) ^ ((hx >> 1) & 7): with the
+    // window column in the swizzle the sixteen lanes of each ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}:
+    // two tile rows) land on sixteen different slots of the 256-byte bank row for every tap (the pixel index did not: 2-way).  The last
     // row block's pixels 180 .. 183 do not exist: they repeat pixel 179 into LDS rows nobody reads.
     unsigned int woff[NDMA];
     int hyx[NDMA];
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(gx::NT, 1) void gconv3x3_x3_kernel(gx::Args p) {
         const int hp = min(8 * rowblk + (lane >> 3), HP - 1);
         const int hy = hp / HWD, hx = hp - hy * HWD;
         hyx[k] = (hy << 8) | hx;
-        woff[k] = (unsigned int)(((hy * p.wd + hx) * p.c + CQ * q) * 2 + (((lane & 7) ^ ((hp >> 1) & 7)) << 4));
+        woff[k] = (unsigned int)(((hy * p.wd + hx) * p.c + CQ * q) * 2 + (((lane & 7) ^ ((hx >> 1) & 7)) << 4));
     }
     auto fetch = [&](const Tile& t, int buf) {
         const unsigned int org = elems(t, -1, -1) * 2u;
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(gx::NT, 1) void gconv3x3_x3_kernel(gx::Args p) {
             const int hp = (py + ky) * HWD + px + kx;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int off = hp * 128 + (((4 * nb + 2 * s + h) ^ ((hp >> 1) & 7)) << 4);
+                const int off = hp * 128 + (((4 * nb + 2 * s + h) ^ (((px + kx) >> 1) & 7)) << 4);
                 f[2 * s] = *reinterpret_cast<const half8*>(yh + off);
                 f[2 * s + 1] = *reinterpret_cast<const half8*>(yh + PLANE_B + off);
             }

@@ -31,11 +31,11 @@ constexpr int WH = 2 * TH + 1, WW = 2 * TW + 1, WP = WH * WW;    // conv1a windo
 constexpr int IH = WH + 2, IW = WW + 2, IP = IH * IW;            // image window: 19 x 35 = 665 pixels
 constexpr int NT = 512, NBLK = (WP + 31) / 32;                   // 18 pixel blocks of conv1a
 constexpr int KA = 48;                                           // conv1a's K: 9 taps x 4 channels = 36, padded to three 16-deep steps
-constexpr int Y_PLANE = ((WP + 7) / 8 * 8) * 32 * 2;                // 36 352 bytes (rows are permuted inside groups of eight pixels)
+constexpr int Y_PLANE = WH * 36 * 32 * 2;                         // 39 168 bytes: 17 window rows of 36 pixel rows (c1::RW; columns permuted in eights)
 constexpr int W_PLANE = 9 * 64 * 32 * 2;                         // 36 864
 constexpr int I_PLANE = IP * 4 * 2;                              // 5 320
 constexpr int OFF_Y = 0, OFF_W = OFF_Y + 2 * Y_PLANE, OFF_I = OFF_W + 2 * W_PLANE;
-constexpr int SMEM_BYTES = OFF_I + 2 * I_PLANE;                  // 157 072
+constexpr int SMEM_BYTES = OFF_I + 2 * I_PLANE;                  // 162 704 of the CU's 163 840
 static_assert(Y_PLANE % 16 == 0 && W_PLANE % 16 == 0, "16-byte aligned regions");
 
 struct Args {
@@ -51,13 +51,17 @@ struct Args {
 
 __device__ __forceinline__ int rowoff(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-// Window planes: 64-byte rows (32 channels of a pixel).  conv1b reads them with a pixel stride of 2 (16 lanes = 16 pixels 2 apart),
-// so the row a pixel lives in and the 16-byte slot swizzle are taken from hp >> 1: physical row = hp with its low three bits rotated
-// (bit 0 -> bit 2: odd pixels go four rows up), slot ^= (hp >> 3) & 3 — the 16 lanes of a fragment read land on the 16 distinct
-// (bank group, slot) positions of the LDS.
-__device__ __forceinline__ int yoff(int hp, int slot) {
-    const int prow = (hp & ~7) | ((hp >> 1) & 3) | ((hp & 1) << 2);
-    return prow * 32 + ((slot ^ ((hp >> 3) & 3)) << 3);
+// Window planes: 64-byte rows (32 channels of a pixel), window rows RW pixel rows apart.  conv1b reads them with a pixel stride of
+// 2, a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} — the sixteen output columns of the tile,
+// split over two of its rows — and a group is conflict-free when its lanes hit sixteen different (row mod 4, slot) positions of the
+// 256-byte bank row.  Both are taken from the window COLUMN x = 2 ox + kx: the physical row is x with its low three bits rotated
+// (bit 0 -> bit 2: row mod 4 = (x >> 1) & 3, RW % 4 == 0 keeps that through the row pitch) and the slot is ^ (x >> 3) & 3, so the
+// sixteen consecutive x >> 1 of a group give the sixteen positions whatever rows they sit in.  (Round 4's first layout swizzled with
+// the pixel index y * 33 + x: 2-way, SQ_LDS_BANK_CONFLICT 2.56 per LDS instruction, profiles/r04_pmc_summary.md.)
+constexpr int RW = 36;
+__device__ __forceinline__ int yoff(int y, int x, int slot) {
+    const int prow = y * RW + ((x & ~7) | ((x >> 1) & 3) | ((x & 1) << 2));
+    return prow * 32 + ((slot ^ ((x >> 3) & 3)) << 3);
 }
 
 }  // namespace c1
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
                 if (hpr < WP) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const int off = yoff(hp, g4) + 4 * h;      // channels 8 g4 + 4 h + 0..3 of the half
+                        const int off = yoff(wy, wx, g4) + 4 * h;      // channels 8 g4 + 4 h + 0..3 of the half
                         *reinterpret_cast<half4*>(&y_h[off]) = hi[g4];
                         *reinterpret_cast<half4*>(&y_l[off]) = lo[g4];
                     }
@@ -195,11 +199,10 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
 #pragma unroll 1
             for (int tap = (p.abl & 2) ? 9 : 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
-                const int hp = (2 * oy + ky) * WW + 2 * ox + kx;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int slot = 2 * ks + h;
-                    const int aoff = yoff(hp, slot);
+                    const int aoff = yoff(2 * oy + ky, 2 * ox + kx, slot);
                     const int boff = tap * 2048 + brow + swz(slot, r) * 8;      // row 32 wn + r: same swizzle as r
                     const half8 ah = *reinterpret_cast<const half8*>(&y_h[aoff]);
                     const half8 al = *reinterpret_cast<const half8*>(&y_l[aoff]);

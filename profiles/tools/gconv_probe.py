@@ -30,3 +30,7 @@ timed("grouped 3x3, vector ALU (fp32 in)", lambda: ops.conv3x3_grouped_nhwc(x, w
 timed("grouped 3x3, matrix pipe (planes in)", lambda: ops.conv3x3_grouped_planes(hi, lo, w, s, t, 32, True))
 timed("1x1 256 -> 256, fp32 out", lambda: ops.conv2d_nhwc(x, w1, None, s, t, ks=1, relu=True, precision="x3"))
 timed("1x1 256 -> 256, planes out", lambda: ops.conv2d_nhwc_planes(x, w1, None, s, t, ks=1, relu=True))
+w3 = torch.randn(256, 1, 1, 256, device=dev) * 0.05
+res = torch.randn(16, 120, 160, 256, device=dev)
+y2 = torch.randn(16, 120, 160, 256, device=dev)
+timed("1x1 256 -> 256 + residual, fp32 out", lambda: ops.conv2d_nhwc(y2, w3, None, s, t, residual=res, ks=1, relu=True, precision="x3"))
