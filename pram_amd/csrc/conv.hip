@@ -418,23 +418,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
 // of conv_x3w_kernel: the two kernels agree bit for bit (tests/test_gpu_round3.py::test_conv3x3_halo_equals_chunked).
 namespace halo {
 constexpr int TH = 8, TW = 32, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;      // 340 window pixels
-constexpr int BK = 32, BN = 256, NT = 512, MI = 4, WN = 4;
+constexpr int BK = 32, NT = 512;
 constexpr int NL = (HP * 8 + NT - 1) / NT;                                      // float4 loads per thread and slab (6)
+// WN = 4: 256 output channels per workgroup, waves as 2 x 4, four tile rows each (the 256-channel layers); WN = 2: 128 channels,
+// waves as 4 x 2, two tile rows each (conv2a, 64 -> 128 at 240 x 320: 880 -> 800 us).  Same arithmetic and order either way.
+// (For the 128-channel form two more shapes were measured and dropped — 4 x 32-pixel tiles with one window stage so that two
+// 4-wave workgroups share a CU, and that with a ring of three weight stages: 816 and 822 us.)
+template <int WN_>
 struct alignas(16) Smem {
     _Float16 ah[2][HP * BK];
     _Float16 al[2][HP * BK];
-    _Float16 bh[2][BN * BK];
-    _Float16 bl[2][BN * BK];
-};      // 152 576 bytes
+    _Float16 bh[2][WN_ * 64 * BK];
+    _Float16 bl[2][WN_ * 64 * BK];
+};      // 152 576 bytes (WN_ = 4), 119 808 (WN_ = 2)
 }  // namespace halo
 
+template <int WN>
 __global__ __launch_bounds__(halo::NT, 1) void conv3x3_x3h_kernel(ConvArgs p, const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
                                                                   float inv, int tiles_x, int tiles_y) {
     using namespace halo;
     using gemmx3::half4;
     using gemmx3::half8;
+    constexpr int BN = WN * 64, MI = TH / (NT / 64 / WN);      // 256 channels x 4 rows per wave, or 128 x 2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    Smem<WN>& s = *reinterpret_cast<Smem<WN>*>(smem_raw);
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int tn = id % p.tiles_n;
@@ -834,17 +841,24 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
     } while (0)
     static const char* force = getenv("PRAM_X3_TILE");
     const char* halo_env = getenv("PRAM_CONV_HALO");      // "0": the per-tap staging kernel for every layer (profiling / the equality test; read per call)
-    if (ks == 3 && stride == 1 && cout >= 256 && !(force && force[0] == 'n') && !(halo_env && halo_env[0] == '0')) {
+    // PRAM_CONV_HALO: "0" = never, "w" = the 256-channel form only (what the 128-channel form buys is measured with it)
+    if (ks == 3 && stride == 1 && (cout >= 256 || (cout == 128 && !(halo_env && halo_env[0] == 'w'))) && !(force && force[0] == 'n') &&
+        !(halo_env && halo_env[0] == '0')) {
         const int tiles_x = cdiv(p.wo, halo::TW), tiles_y = cdiv(p.ho, halo::TH);
         p.tiles_m = batch * tiles_x * tiles_y;
-        p.tiles_n = cdiv(cout, halo::BN);
+        const bool narrow = cout <= 128;      // one 128-channel column tile
+        p.tiles_n = cdiv(cout, narrow ? 128 : 256);
         if ((long)p.tiles_m * p.tiles_n >= 224) {
             static bool hattr = false;
             if (!hattr) {
-                (void)hipFuncSetAttribute((const void*)conv3x3_x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(halo::Smem));
+                (void)hipFuncSetAttribute((const void*)conv3x3_x3h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(halo::Smem<4>));
+                (void)hipFuncSetAttribute((const void*)conv3x3_x3h_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(halo::Smem<2>));
                 hattr = true;
             }
-            hipLaunchKernelGGL(conv3x3_x3h_kernel, dim3(p.tiles_m * p.tiles_n), dim3(halo::NT), sizeof(halo::Smem), st, p, wh, wl, inv, tiles_x, tiles_y);
+            if (narrow)
+                hipLaunchKernelGGL(conv3x3_x3h_kernel<2>, dim3(p.tiles_m * p.tiles_n), dim3(halo::NT), sizeof(halo::Smem<2>), st, p, wh, wl, inv, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(conv3x3_x3h_kernel<4>, dim3(p.tiles_m * p.tiles_n), dim3(halo::NT), sizeof(halo::Smem<4>), st, p, wh, wl, inv, tiles_x, tiles_y);
             return pram_launch_status("pram_conv2d_nhwc_x3_f32");
         }
     }

@@ -516,9 +516,10 @@ print("RCCL_ONE_RANK_OK")
 
 
 # ------------------------------------------------------------------------------------------------ 3x3 conv with the window in LDS
-@pytest.mark.parametrize("shape", [(4, 120, 160, 256, 256), (12, 60, 80, 128, 256), (12, 37, 45, 64, 512), (16, 120, 160, 32, 256)])
+@pytest.mark.parametrize("shape", [(4, 120, 160, 256, 256), (12, 60, 80, 128, 256), (12, 37, 45, 64, 512), (16, 120, 160, 32, 256),
+                                   (2, 240, 320, 64, 128), (9, 37, 45, 96, 128)])      # the last two: the 128-channel form (conv2a)
 def test_conv3x3_halo_equals_chunked(dev, shape, monkeypatch):
-    """3x3 / stride-1 layers with >= 256 output channels keep the input window of a workgroup resident in LDS (staged and split once
+    """3x3 / stride-1 layers with >= 256 (or exactly 128) output channels keep the input window of a workgroup resident in LDS (staged and split once
     per 32-channel slab instead of once per tap): same K order, same products per accumulator -> the SAME bits as the per-tap kernel
     (PRAM_CONV_HALO=0), with bias, BatchNorm scale / shift, residual and ReLU, on whole and on ragged tiles; both against fp64."""
     B, Hh, Ww, cin, cout = shape
