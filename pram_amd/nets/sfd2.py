@@ -134,7 +134,7 @@ class ResNet4x(blk.PackedCache, nn.Module):
                 o4 = ops.resblock_nhwc(o4, P[p + ".w1"], P[p + ".s1"], P[p + ".t1"], P[p + ".w2"], P[p + ".s2"], P[p + ".t2"],
                                        P[p + ".w3"], P[p + ".s3"], P[p + ".t3"])
                 continue
-            if ops.GROUPED_X3 and ops.gemm_prec() == "x3" and o4.shape[-1] % 64 == 0:
+            if ops.GROUPED_X3 and ops.gemm_prec() == "x3" and o4.shape[-1] % 64 == 0 and o4.numel() < (1 << 29):      # (32-bit buffer offsets)
                 # the 1x1 hands its result over as split fp16 planes; the grouped 3x3 runs on the matrix pipe from them
                 yh, yl = ops.conv2d_nhwc_planes(o4, P[p + ".w1"], None, P[p + ".s1"], P[p + ".t1"], ks=1, relu=True)
                 y = ops.conv3x3_grouped_planes(yh, yl, P[p + ".w2"], P[p + ".s2"], P[p + ".t2"], groups=o4.shape[-1] // 8, relu=True)
