@@ -957,7 +957,7 @@ extern "C" int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int
 // HBM to LDS by DMA, no register and no vector instruction in between, and a persistent workgroup (one per CU, 8 waves, a
 // channel quarter = 64 channels = 8 groups, walking 8 x 16-pixel tiles) keeps the next tile's window in flight under the
 // current tile's MFMAs: three window buffers of 2 x 184 pixels x 128 bytes (the 16-byte slot swizzled with the window column through the
-// source addresses; a pixel outside the image reads a page of zeros).  The weights never touch LDS: a lane's column is one output
+// source addresses; a pixel outside the image is addressed past the end of the buffer, which reads as zeros).  The weights never touch LDS: a lane's column is one output
 // channel, its 72 weights (two planes) stay in registers for the kernel's life and a select zeroes them for the k-steps of the
 // other groups.  out[pixel][channel]: lanes are channels, a store instruction writes 128 contiguous bytes per pixel.
 // fp32-class (three fp16 products, fp32 accumulation), not the fp32 FMA chain of gconv3x3_kernel: the two agree to ~3e-7
