@@ -378,6 +378,14 @@ int pram_conv3x3_grouped_nhwc_f32(const float* in, int batch, int h, int w, int 
                                   const float* scale, const float* shift, float* out, int groups,
                                   int relu, void* stream);
 
+/* pram_conv2d_nhwc_x3_f32 followed, in the same kernel, by F.normalize over the channels of every output pixel (x / max(||x||, 1e-12)):
+ * SFD2's descriptor head (convDb -> normalize, reference nets/sfd2.py:331-333) without the second pass over the map.  cout <= 128 (one
+ * workgroup holds a pixel's whole channel vector), cin % 32 == 0.  The squared sums are added in another order than
+ * pram_l2norm_rows_f32 adds them: the two agree to rounding, not bit for bit. */
+int pram_conv2d_nhwc_x3_l2norm_f32(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,
+                                   float w_scale, const float* bias, const float* scale, const float* shift, const float* residual,
+                                   float* out, int cout, int ks, int stride, int relu, void* stream);
+
 /* pram_conv2d_nhwc_x3_f32 whose result leaves as the split operand of the next split-fp16 layer instead of fp32: out_hi =
  * fp16(16 y), out_lo = fp16(16 y - out_hi), [batch][ho][wo][cout] each — the same four bytes per value, and the consumer needs
  * neither registers nor vector instructions to stage it (LDS-DMA).  cin % 32 == 0, cout even; |y| >= 4095 is reported through the

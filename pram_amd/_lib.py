@@ -47,6 +47,7 @@ _SIGS = {
     "pram_attention_x3_colmean_f32": (I, [P, P, I, P, P, I, P, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_h16t_f32": (I, [P, I, P, I, P, P, I, P, P, P, I, I, I, I, F, I, P]),
     "pram_attention_x3_vt": (I, [P, P, I, P, P, P, I, I, I, P]),
+    "pram_conv2d_nhwc_x3_l2norm_f32": (I, [P, I, I, I, I, P, P, F, P, P, P, P, P, I, I, I, I, P]),
     "pram_conv2d_nhwc_x3_planes": (I, [P, I, I, I, I, P, P, F, P, P, P, P, P, P, I, I, I, I, P]),
     "pram_conv3x3_grouped_planes_x3_f32": (I, [P, P, I, I, I, I, P, P, F, P, P, P, I, I, P]),
     "pram_sfd2_conv1_x3_f32": (I, [P, I, I, I, P, P, F, P, P, P, P, P, F, P, P, P, P, P]),

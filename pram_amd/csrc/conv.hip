@@ -75,6 +75,71 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     }
 }
 
+// conv_epilogue followed by F.normalize over the channels of every output pixel (x / max(||x||, 1e-12): the descriptor head,
+// reference nets/sfd2.py:333): the workgroup's BN columns are the pixel's whole channel vector (cout <= BN, one column tile), so
+// the squared sums are reduced across the 32 lanes of a half-wave (DPP within the 16-lane rows, one swizzle across them) and
+// across the WN waves of a tile row through `scratch` ([WN][BM] floats of LDS the main loop is done with) — instead of a second
+// kernel that reads the map back and writes it again.
+template <int MI, int WN>
+__device__ __forceinline__ void conv_epilogue_l2norm(const ConvArgs& p, f32x16 (&acc)[MI][2], int row0, int col0, int BM, float* scratch) {
+    using gemm::acc_row;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int nlast = p.cout - 1, mlast = p.m - 1;
+    const int rloc = wm * 32 * MI;                      // first tile row of this wave
+    const int rbase = row0 + rloc;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = col0 + wn * 64 + ni * 32 + r;
+        const int cc = min(col, nlast);
+        const float bi = p.bias ? p.bias[cc] : 0.f;
+        const float sc = p.scale ? p.scale[cc] : 1.f;
+        const float sh = p.scale ? p.shift[cc] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[mi][ni][e] + bi;
+                if (p.scale) v = v * sc + sh;
+                if (p.residual) v += p.residual[(size_t)min(rbase + acc_row(mi, e, h), mlast) * p.cout + cc];
+                if (p.relu) v = fmaxf(v, 0.f);
+                acc[mi][ni][e] = col < p.cout ? v : 0.f;
+            }
+    }
+    __syncthreads();                                    // every wave is out of the main loop: its LDS is free
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float s = acc[mi][0][e] * acc[mi][0][e] + acc[mi][1][e] * acc[mi][1][e];
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, false));     // row_half_mirror
+            s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, false));     // row_mirror
+            s += __shfl_xor(s, 16, 64);                                                                                          // the other 16-lane row of the half
+            if (r == 0) scratch[wn * BM + rloc + acc_row(mi, e, h)] = s;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tr = rloc + acc_row(mi, e, h);
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) tot += scratch[w * BM + tr];
+            const float d = fmaxf(sqrtf(tot), 1e-12f);
+            const int row = row0 + tr;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = col0 + wn * 64 + ni * 32 + r;
+                if (row < p.m && col < p.cout) p.out[(size_t)row * p.cout + col] = acc[mi][ni][e] / d;
+            }
+        }
+}
+
 // The epilogue of a layer whose result is the split operand of the next split-fp16 layer: instead of fp32 it leaves as fp16 planes
 // hi = fp16(16 v), lo = fp16(16 v - hi), [m][cout] each — what that layer's staging would compute, done once here, and the same
 // four bytes per value.  bias -> BN scale/shift -> residual -> ReLU as conv_epilogue, with the 16 folded into the constants (a
@@ -263,7 +328,7 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
 
 // split-fp16 variant (gemm_core_x3.h): wh / wl = [cout][ks][ks][cin] * w_scale split into two fp16 planes on the host,
 // cin % 32 == 0 (a 32-deep chunk never straddles taps); the im2col rows are split while they are staged.
-template <int MI, int WN>
+template <int MI, int WN, bool L2N = false>
 __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, const _Float16* __restrict__ wh,
                                                                  const _Float16* __restrict__ wl, float inv) {
     using namespace gemmx3;
@@ -328,7 +393,8 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
-    conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
+    if constexpr (L2N) conv_epilogue_l2norm<MI, WN>(p, acc, row0, col0, BM, reinterpret_cast<float*>(&smem));
+    else conv_epilogue<MI, WN>(p, acc, row0, col0, BM, BN);
 }
 
 // wide-tile split-fp16 convolution (gemm_core_x3w.h): 256 output pixels x 256 channels per 512-thread workgroup — the 256-channel
@@ -879,6 +945,33 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
     else { if (mi == 2) LAUNCHX3(2, 2); else LAUNCHX3(1, 2); }
 #undef LAUNCHX3
     return pram_launch_status("pram_conv2d_nhwc_x3_f32");
+}
+
+/* pram_conv2d_nhwc_x3_f32 followed by F.normalize over the channels of every output pixel (x / max(||x||, 1e-12)) in the same
+   kernel: SFD2's descriptor head (convDb -> normalize, reference nets/sfd2.py:331-333).  cout <= 128 (a workgroup holds a pixel's
+   whole channel vector), cin % 32 == 0. */
+extern "C" int pram_conv2d_nhwc_x3_l2norm_f32(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,
+                                              float w_scale, const float* bias, const float* scale, const float* shift,
+                                              const float* residual, float* out, int cout, int ks, int stride, int relu, void* stream) {
+    PRAM_REQUIRE(in && wgt_hi && wgt_lo && out, "pram_conv2d_nhwc_x3_l2norm_f32: null pointer");
+    PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_x3_l2norm_f32: ks must be 1 or 3");
+    PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_x3_l2norm_f32: stride must be 1 or 2");
+    PRAM_REQUIRE(cin % 32 == 0 && w_scale > 0.f, "pram_conv2d_nhwc_x3_l2norm_f32: cin=%d must be a multiple of 32", cin);
+    PRAM_REQUIRE(cout > 0 && cout <= 128, "pram_conv2d_nhwc_x3_l2norm_f32: cout=%d must be at most 128", cout);
+    PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_x3_l2norm_f32: scale and shift go together");
+    if (batch == 0) return PRAM_OK;
+    const int pad = ks / 2;
+    ConvArgs p{in, nullptr, bias, scale, shift, residual, out, batch, h, w, cin, cout, ks, stride, relu};
+    p.ho = (h + 2 * pad - ks) / stride + 1;
+    p.wo = (w + 2 * pad - ks) / stride + 1;
+    p.m = batch * p.ho * p.wo;
+    p.k = ks * ks * cin;
+    p.status = pram_status_ptr();
+    p.tiles_m = cdiv(p.m, gemmx3::Cfg<2, 2>::BM);
+    p.tiles_n = 1;
+    hipLaunchKernelGGL((conv_x3_kernel<2, 2, true>), dim3(p.tiles_m), dim3(gemmx3::NT), 0, (hipStream_t)stream, p, (const _Float16*)wgt_hi,
+                       (const _Float16*)wgt_lo, 1.0f / (gemmx3::ACT_SCALE * w_scale));
+    return pram_launch_status("pram_conv2d_nhwc_x3_l2norm_f32");
 }
 
 /* pram_conv2d_nhwc_x3_f32 with the result as the split operand of the next split-fp16 layer: out_hi = fp16(16 y),

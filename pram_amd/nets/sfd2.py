@@ -153,8 +153,7 @@ class ResNet4x(blk.PackedCache, nn.Module):
     def _desc_head(self, P, o4):
         da = ops.conv2d_nhwc(o4, P["convDa.w0"], P["convDa.b0"], P["convDa.s0"], P["convDa.t0"], ks=3, relu=True)
         da = ops.conv2d_nhwc(da, P["convDa.w3"], P["convDa.b3"], ks=3)
-        desc = ops.conv2d_nhwc(da, P["convDb.w"], P["convDb.b"], ks=1)
-        return ops.l2norm_rows_(desc)           # F.normalize(desc, dim=1)
+        return ops.conv2d_nhwc(da, P["convDb.w"], P["convDb.b"], ks=1, l2norm=True)           # convDb, then F.normalize(desc, dim=1)
 
     @staticmethod
     def _nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:

@@ -973,9 +973,10 @@ def adagml_scatter(matches0, mscores0, ind0, ind1, lens0, m_full):
 
 # ------------------------------------------------------------------------------------- SFD2
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=None, residual=None, ks: int = 3,
-                stride: int = 1, relu: bool = False, precision: Optional[str] = None) -> torch.Tensor:
+                stride: int = 1, relu: bool = False, precision: Optional[str] = None, l2norm: bool = False) -> torch.Tensor:
     """x [B,H,W,Cin] contiguous NHWC; w [Cout,ks,ks,Cin].  precision: see linear() (conv1a's 4-channel input always runs
-    on the exact-fp32 kernel)."""
+    on the exact-fp32 kernel).  l2norm: F.normalize over the channels of every output pixel behind the layer — inside the
+    convolution's epilogue on the split-fp16 path when Cout <= 128, as a second kernel (l2norm_rows_) otherwise."""
     L = _lib.load()
     _chk(x, "x")
     assert x.is_contiguous() and w.is_contiguous()
@@ -987,18 +988,22 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, scale=None, shift=N
     prec = _check_precision(_tl("forced") or precision or gemm_prec())
     if prec == "x3" and Cin % 32 == 0:
         wh, wl, ws = split_weight(w)
+        if l2norm and Cout <= 128 and FUSED_L2NORM:
+            _lib.check(L.pram_conv2d_nhwc_x3_l2norm_f32(_p(x), B, H, W, Cin, _p(wh), _p(wl), ws, _p(bias), _p(scale), _p(shift), _p(residual),
+                                                        _p(out), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_x3_l2norm_f32")
+            return out
         _lib.check(L.pram_conv2d_nhwc_x3_f32(_p(x), B, H, W, Cin, _p(wh), _p(wl), ws, _p(bias), _p(scale), _p(shift), _p(residual),
                                              _p(out), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_x3_f32")
-        return out
-    if prec == "f16" and Cin % 64 == 0:
+    elif prec == "f16" and Cin % 64 == 0:
         _lib.check(L.pram_conv2d_nhwc_f16_f32(_p(x), B, H, W, Cin, _p(_w16(w)), _p(bias), _p(scale), _p(shift), _p(residual),
                                               _p(out), Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f16_f32")
-        return out
-    _lib.check(L.pram_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(w), _p(bias), _p(scale), _p(shift), _p(residual), _p(out),
-                                      Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f32")
-    return out
+    else:
+        _lib.check(L.pram_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(w), _p(bias), _p(scale), _p(shift), _p(residual), _p(out),
+                                          Cout, ks, stride, int(relu), _st()), "pram_conv2d_nhwc_f32")
+    return l2norm_rows_(out) if l2norm else out
 
 
+FUSED_L2NORM = _os.environ.get("PRAM_FUSED_L2NORM", "1") != "0"      # split-fp16 path: F.normalize inside the producing convolution
 GROUPED_X3 = _os.environ.get("PRAM_GROUPED_X3", "1") != "0"      # split-fp16 path: the grouped 3x3 on the matrix pipe (0: vector ALU)
 
 

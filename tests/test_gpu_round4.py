@@ -341,3 +341,32 @@ def test_conv_writes_the_next_layers_split_operand(dev, shape):
     if Cout == 256:
         ops.conv2d_nhwc_planes(xd, wd, None, sc * 4000.0, sh, ks=1, relu=True)
         assert ops.x3_range_exceeded(dev)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 32, 256, 128, 1), (1, 13, 21, 64, 96, 1), (3, 9, 7, 32, 64, 3), (16, 120, 160, 256, 128, 1)])
+def test_conv_with_channel_normalisation_in_its_epilogue(dev, shape, monkeypatch):
+    """pram_conv2d_nhwc_x3_l2norm_f32 = convolution -> F.normalize over the channels of each pixel in one kernel, against the two
+    kernels (same values, another summation order: agreement to rounding) and an fp64 reference; ragged row tiles, narrow outputs,
+    a 3 x 3 layer, the descriptor head's own shape; an all-zero pixel stays zero (the 1e-12 floor)."""
+    B, Hh, Ww, cin, cout, ks = shape
+    x = W.normal(13, f"ln/x{shape}", (B, Hh, Ww, cin), 1.0)
+    x[0, 0, 0] = 0.0
+    w = W.normal(13, f"ln/w{shape}", (cout, ks, ks, cin), (ks * ks * cin) ** -0.5)
+    bias = W.normal(13, f"ln/b{cout}", (cout,), 0.1)
+    xd, wd = x.to(dev), w.to(dev)
+    bd = None if ks == 3 else bias.to(dev)      # (without a bias the zero pixel of the 3 x 3 case is not zero either: its neighbours)
+    monkeypatch.setattr(ops, "FUSED_L2NORM", True)
+    got = ops.conv2d_nhwc(xd, wd, bd, ks=ks, precision="x3", l2norm=True)
+    monkeypatch.setattr(ops, "FUSED_L2NORM", False)
+    two = ops.conv2d_nhwc(xd, wd, bd, ks=ks, precision="x3", l2norm=True)
+    assert float((got - two).abs().max()) <= 4e-7
+    if B * Hh * Ww <= 4096:
+        r = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None if ks == 3 else bias.double(), padding=ks // 2)
+        r = torch.nn.functional.normalize(r, dim=1).permute(0, 2, 3, 1)
+        assert float((got.double().cpu() - r).abs().max()) <= 2e-6
+    n = got.double().pow(2).sum(-1).sqrt()
+    assert float((n - 1.0).abs().max()) <= 1e-6 or ks == 1      # unit vectors ...
+    if ks == 1:
+        wz = torch.zeros_like(wd)
+        z = ops.conv2d_nhwc(xd, wz, None, ks=1, precision="x3", l2norm=True)
+        assert float(z.abs().max()) == 0.0                        # ... and zero stays zero
