@@ -406,14 +406,15 @@ int pram_conv3x3_grouped_planes_x3_f32(const void* in_hi, const void* in_lo, int
 /* SFD2's first two convolutions (nets/sfd2.py:135-139,281-282: conv1a 3 -> 64 3x3 stride 1, conv1b 64 -> 64 3x3 stride 2, each bias
  * -> BN -> ReLU) in ONE launch on the split-fp16 path: the 480 x 640 x 64 map between them (1.26 GB for 16 frames: the largest
  * round trip of the step) never exists — a workgroup computes the (2 * 8 + 1) x (2 * 16 + 1) window of conv1a outputs it needs
- * from the image, in LDS.  img: NHWC4 fp32 (pram_image_to_nhwc4_f32); out [batch][(h - 1) / 2 + 1][(w - 1) / 2 + 1][64].
+ * from the image, in LDS.  img: NHWC4 fp32 (pram_image_to_nhwc4_f32), or with img_nchw3 != 0 the reference's own NCHW layout
+ * [batch][3][h][w] (the repack kernel is then not needed); out [batch][(h - 1) / 2 + 1][(w - 1) / 2 + 1][64].
  * wa: conv1a's [64][3][3][4] weights flattened to [64][36], zero-padded to [64][48], * wa_scale, as (hi, lo) fp16 planes;
  * wb: conv1b's [64][3][3][64] weights * wb_scale as (hi, lo) planes (the operand of pram_conv2d_nhwc_x3_f32); b? / s? / t?: bias and
  * eval-mode BatchNorm scale / shift of each layer.  fp32-class, not bit-identical to the two-kernel form (whose conv1a is the
  * exact-fp32 MFMA kernel). */
 int pram_sfd2_conv1_x3_f32(const float* img, int batch, int h, int w, const void* wa_hi, const void* wa_lo, float wa_scale,
                            const float* ba, const float* sa, const float* ta, const void* wb_hi, const void* wb_lo, float wb_scale,
-                           const float* bb, const float* sb, const float* tb, float* out, void* stream);
+                           const float* bb, const float* sb, const float* tb, float* out, int img_nchw3, void* stream);
 
 /* One ResBlock of SFD2's conv4 (nets/sfd2.py:107-124: 1x1 -> BN -> ReLU -> 3x3 groups = 32 -> BN -> ReLU -> 1x1 -> BN -> + identity
  * -> ReLU; 256 channels) on the split-fp16 path as ONE kernel: a workgroup owns 8 x 16 pixels, the two intermediate feature maps

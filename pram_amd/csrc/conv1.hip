@@ -39,7 +39,7 @@ constexpr int SMEM_BYTES = OFF_I + 2 * I_PLANE;                  // 162 704 of t
 static_assert(Y_PLANE % 16 == 0 && W_PLANE % 16 == 0, "16-byte aligned regions");
 
 struct Args {
-    const float* img; float* out;                  // NHWC4 image [b][h][w][4]; out [b][ho][wo][64]
+    const float* img; float* out;                  // image: NHWC4 [b][h][w][4], or (nchw3) the reference's NCHW [b][3][h][w]; out [b][ho][wo][64]
     const _Float16* wah; const _Float16* wal; float inva;      // conv1a weight planes [64][KA] * scale
     const float* ba; const float* sa; const float* ta;
     const _Float16* wbh; const _Float16* wbl; float invb;      // conv1b weight planes [64][3][3][64] * scale
@@ -47,6 +47,7 @@ struct Args {
     int batch, h, wd, ho, wo, tiles_x, tiles_y;
     unsigned int* status;
     int abl;      // profiling only (PRAM_C1_ABLATE): 1 = no conv1a blocks, 2 = no conv1b taps, 4 = no weight DMA after the first
+    int nchw3;
 };
 
 __device__ __forceinline__ int rowoff(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
@@ -109,7 +110,14 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
                 const int wy = ip / IW, wx = ip - wy * IW;
                 const int gy = ay0 - 1 + wy, gx = ax0 - 1 + wx;
                 const bool in = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.wd;
-                float4 v = img4[(size_t)min(max(gy, 0), p.h - 1) * p.wd + min(max(gx, 0), p.wd - 1)];
+                const size_t px = (size_t)min(max(gy, 0), p.h - 1) * p.wd + min(max(gx, 0), p.wd - 1);
+                float4 v;
+                if (p.nchw3) {      // three planes of the image as the caller holds it: the repack kernel and its 16-byte pixels are skipped
+                    const float* pl = p.img + (size_t)b * 3 * p.h * p.wd + px;
+                    v = make_float4(pl[0], pl[(size_t)p.h * p.wd], pl[2 * (size_t)p.h * p.wd], 0.f);
+                } else {
+                    v = img4[px];
+                }
                 if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 half4 hi, lo;
                 gemmx3::split4(v, gemmx3::ACT_SCALE, hi, lo, amax);
@@ -244,14 +252,15 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
    as per-channel scale / shift of each layer. */
 extern "C" int pram_sfd2_conv1_x3_f32(const float* img, int batch, int h, int w, const void* wa_hi, const void* wa_lo, float wa_scale,
                                       const float* ba, const float* sa, const float* ta, const void* wb_hi, const void* wb_lo,
-                                      float wb_scale, const float* bb, const float* sb, const float* tb, float* out, void* stream) {
+                                      float wb_scale, const float* bb, const float* sb, const float* tb, float* out, int img_nchw3,
+                                      void* stream) {
     PRAM_REQUIRE(img && out && wa_hi && wa_lo && wb_hi && wb_lo && ba && sa && ta && bb && sb && tb, "pram_sfd2_conv1_x3_f32: null pointer");
     PRAM_REQUIRE(batch >= 0 && h > 0 && w > 0 && wa_scale > 0.f && wb_scale > 0.f, "pram_sfd2_conv1_x3_f32: bad sizes");
     if (batch == 0) return PRAM_OK;
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     c1::Args p{img, out, (const _Float16*)wa_hi, (const _Float16*)wa_lo, 1.0f / (gemmx3::ACT_SCALE * wa_scale), ba, sa, ta,
                (const _Float16*)wb_hi, (const _Float16*)wb_lo, 1.0f / (gemmx3::ACT_SCALE * wb_scale), bb, sb, tb,
-               batch, h, w, ho, wo, cdiv(wo, c1::TW), cdiv(ho, c1::TH), pram_status_ptr(), 0};
+               batch, h, w, ho, wo, cdiv(wo, c1::TW), cdiv(ho, c1::TH), pram_status_ptr(), 0, img_nchw3 != 0};
     { const char* e = getenv("PRAM_C1_ABLATE"); p.abl = e ? atoi(e) : 0; }
     static bool attr = false;
     if (!attr) {

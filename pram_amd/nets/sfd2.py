@@ -112,12 +112,13 @@ class ResNet4x(blk.PackedCache, nn.Module):
     def _backbone(self, image: torch.Tensor):
         blk.require_cuda(image, "ResNet4x")
         P = self._packed_get(self._build_packed)
-        x = ops.image_to_nhwc4(image.float())
+        fused1 = FUSED_CONV1 and ops.gemm_prec() in ("x3", "f16")
+        x = image.float().contiguous() if fused1 and image.shape[-1] != 4 else ops.image_to_nhwc4(image.float())
 
         def cbr(x, n, stride=1):
             return ops.conv2d_nhwc(x, P[n + ".w"], P[n + ".b"], P[n + ".s"], P[n + ".t"], ks=3, stride=stride, relu=True)
 
-        if FUSED_CONV1 and ops.gemm_prec() in ("x3", "f16"):
+        if fused1:
             # conv1a -> conv1b in one launch: the 480 x 640 x 64 map between them never goes to HBM (split-fp16 arithmetic; the fp16
             # path takes it too: faster than its own two kernels and more accurate)
             o1b = ops.sfd2_conv1(x, P["conv1a.w"], P["conv1a.b"], P["conv1a.s"], P["conv1a.t"],

@@ -1068,10 +1068,16 @@ def resblock_nhwc(x: torch.Tensor, w1: torch.Tensor, s1, t1, w2: torch.Tensor, s
 def sfd2_conv1(x4: torch.Tensor, wa: torch.Tensor, ba, sa, ta, wb: torch.Tensor, bb, sb, tb) -> torch.Tensor:
     """SFD2's conv1a -> conv1b (3x3 / stride 1 / 3 -> 64, then 3x3 / stride 2 / 64 -> 64, each bias -> BN -> ReLU; nets/sfd2.py:135-139,
     281-282) in ONE launch on the split-fp16 path (pram_sfd2_conv1_x3_f32): the 1.26 GB conv1a map never exists.  x4: the NHWC4 image
-    (image_to_nhwc4); wa [64, 3, 3, 4], wb [64, 3, 3, 64] as conv2d_nhwc takes them.  -> [B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64]."""
+    (image_to_nhwc4) or the fp32 NCHW image [B, 3, H, W] itself; wa [64, 3, 3, 4], wb [64, 3, 3, 64] as conv2d_nhwc takes them.
+    -> [B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64]."""
     L = _lib.load()
-    assert x4.is_contiguous() and x4.shape[-1] == 4 and tuple(wa.shape) == (64, 3, 3, 4) and tuple(wb.shape) == (64, 3, 3, 64)
-    B, H, W, _ = x4.shape
+    assert x4.is_contiguous() and x4.dtype == torch.float32 and tuple(wa.shape) == (64, 3, 3, 4) and tuple(wb.shape) == (64, 3, 3, 64)
+    nchw3 = x4.shape[-1] != 4
+    if nchw3:
+        assert x4.dim() == 4 and x4.shape[1] == 3
+        B, _, H, W = x4.shape
+    else:
+        B, H, W, _ = x4.shape
 
     def pad48(t):      # [64][36] -> [64][48]: K padded to three 16-deep steps, then the usual split
         flat = t.reshape(64, 36).float()
@@ -1082,7 +1088,7 @@ def sfd2_conv1(x4: torch.Tensor, wa: torch.Tensor, ba, sa, ta, wb: torch.Tensor,
     wbh, wbl, wsb = split_weight(wb)
     out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=x4.device, dtype=torch.float32)
     _lib.check(L.pram_sfd2_conv1_x3_f32(_p(x4), B, H, W, _p(wah), _p(wal), wsa, _p(ba), _p(sa), _p(ta), _p(wbh), _p(wbl), wsb,
-                                        _p(bb), _p(sb), _p(tb), _p(out), _st()), "pram_sfd2_conv1_x3_f32")
+                                        _p(bb), _p(sb), _p(tb), _p(out), int(nchw3), _st()), "pram_sfd2_conv1_x3_f32")
     return out
 
 

@@ -279,6 +279,9 @@ def test_fused_conv1(dev, shape):
     e_f, e_2 = float((got.double().cpu() - r).abs().max()), float((two.double().cpu() - r).abs().max())
     assert e_f <= max(2.0 * e_2, 2e-6 * scale), (e_f, e_2, scale)
     assert float((got - two).abs().max()) <= 4e-6 * scale
+    # the image as the caller holds it (NCHW, three planes): the same bits without the repack kernel
+    direct = ops.sfd2_conv1(img.to(dev).contiguous(), wa.to(dev), d["ba"], d["sa"], d["ta"], wb.to(dev), d["bb"], d["sb"], d["tb"])
+    assert torch.equal(direct, got)
     if shape == (2, 96, 128):
         bad = img.clone()
         bad[1, 2, 40, 50] = 5.0e3
