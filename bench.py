@@ -215,16 +215,29 @@ def parity_gate(pipe, sds, matcher_name, images, ref, kpts):
             data = {"descriptors0": out["descriptors"][:1, :nm].cpu(), "keypoints0": kp[None, :nm], "scores0": out["scores"][:1, :nm].cpu(),
                     "descriptors1": ref1["descriptors"].cpu(), "keypoints1": ref1["keypoints"].cpu(), "scores1": ref1["scores"].cpu(),
                     "image_shape0": (1, 3, W_IMG, H), "image_shape1": (1, 3, W_IMG, H)}
-            r = _oracle_matcher(matcher_name)(sds[matcher_name], data)
+            probes = {} if matcher_name == "gml" else None      # (the GML restatement hands out its assignment matrix)
+            r = _oracle_matcher(matcher_name)(sds[matcher_name], data, **({"probes": probes} if probes is not None else {}))
             m_got, s_got = out["matches0"][0, :nm].cpu(), out["matching_scores0"][0, :nm].cpu()
             m_ref, s_ref = r["matches0"][0], r["matching_scores0"][0]
             thr = float(getattr(pipe.matcher, "match_threshold", 0.2))
             # `mscores0 = where(mutual0, max0, 0)` (nets/gml.py:310-314) is a discrete decision too: when the two best entries of a
-            # COLUMN agree to the last bits, which row the column names — and with it whether a row is mutual — can flip between two
-            # fp32 implementations.  For a candidate below the acceptance threshold nothing else changes: both sides report it
-            # unmatched, one side's score is its (small) probability, the other's exactly 0.  Such entries are counted and listed
-            # instead of compared (at most four per query; more fail the gate).
+            # row (or of a column) of the assignment agree to the last bits, which partner is named — and with it whether the row is
+            # mutual — can flip between two fp32 implementations.  For a candidate below the acceptance threshold nothing else
+            # changes: both sides report it unmatched, one side's score is its (small) probability, the other's exactly 0.  Such
+            # entries are counted and listed instead of compared (at most four per query; more fail the gate).
             flip = (m_got == -1) & (m_ref == -1) & ((s_got == 0) ^ (s_ref == 0)) & (torch.maximum(s_got, s_ref) <= thr)
+            gaps = {}
+            if probes and bool(flip.any()):
+                # ... and proven on the oracle's own assignment matrix: the row's two best entries agree to 2e-5 (the two sides may
+                # name different columns), or the row is one of the two best of its column and those agree to 2e-5
+                P = probes["score"][0, :-1, :-1]
+                for i in torch.nonzero(flip).flatten().tolist():
+                    rt = P[i].topk(2)
+                    ct = P[:, int(rt.indices[0])].topk(2)
+                    row_gap, col_gap = float(rt.values[0] - rt.values[1]), float(ct.values[0] - ct.values[1])
+                    gaps[i] = {"row_top2_gap": row_gap, "column_top2_gap": col_gap}
+                    if not (row_gap <= 2e-5 or (i in ct.indices.tolist() and col_gap <= 2e-5)):
+                        flip[i] = False
             d_sc = float(((s_got - s_ref).abs() * (~flip)).max())
             bad = torch.nonzero(m_got != m_ref).flatten()
             # An index can only differ legitimately where the SAME candidate sits on the acceptance threshold itself:
@@ -236,8 +249,8 @@ def parity_gate(pipe, sds, matcher_name, images, ref, kpts):
             res["match"] = {"indices_identical": idx_same, "matches": int((m_ref >= 0).sum()), "scores_maxdiff": float(f"{d_sc:.3e}"),
                             "threshold_ties": len(ties), "mutual_flips_below_threshold": int(flip.sum())}
             if bool(flip.any()):
-                res["match"]["mutual_flips"] = [{"i": int(i), "score_got": float(s_got[i]), "score_ref": float(s_ref[i])}
-                                                for i in torch.nonzero(flip).flatten()[:4]]
+                res["match"]["mutual_flips"] = [{"i": int(i), "score_got": float(s_got[i]), "score_ref": float(s_ref[i]),
+                                                 **(gaps.get(int(i)) or {})} for i in torch.nonzero(flip).flatten()[:4]]
             if bad.numel():
                 res["match"]["differing"] = [
                     {"i": int(i), "got": int(m_got[i]), "ref": int(m_ref[i]), "score_got": float(s_got[i]), "score_ref": float(s_ref[i])}
