@@ -416,17 +416,6 @@ int pram_sfd2_conv1_x3_f32(const float* img, int batch, int h, int w, const void
                            const float* ba, const float* sa, const float* ta, const void* wb_hi, const void* wb_lo, float wb_scale,
                            const float* bb, const float* sb, const float* tb, float* out, int img_nchw3, void* stream);
 
-/* One ResBlock of SFD2's conv4 (nets/sfd2.py:107-124: 1x1 -> BN -> ReLU -> 3x3 groups = 32 -> BN -> ReLU -> 1x1 -> BN -> + identity
- * -> ReLU; 256 channels) on the split-fp16 path as ONE kernel: a workgroup owns 8 x 16 pixels, the two intermediate feature maps
- * never leave the CU (the three-kernel form moves the 315 MB map seven times per block at the bench shape, this one twice).
- * in / out: NHWC fp32 [batch][h][w][256], out != in.  w1 / w3: the [256][256] 1x1 weights * w?_scale as (hi, lo) fp16 planes (the
- * operand format of pram_conv2d_nhwc_x3_f32), w2: fp32 [32][8][3][3][8] (pram_conv3x3_grouped_nhwc_f32's layout), s? / t?: eval-mode
- * BatchNorm folded to per-channel scale / shift.  Same products in the same order as the three kernels: bit-identical results. */
-int pram_resblock_nhwc_x3_f32(const float* in, int batch, int h, int w, const void* w1_hi, const void* w1_lo, float w1_scale,
-                              const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
-                              const void* w3_hi, const void* w3_lo, float w3_scale, const float* s3, const float* t3,
-                              float* out, void* stream);
-
 /* NCHW [b][3][h][w] -> NHWC4 [b][h][w][4] (zero 4th channel) */
 int pram_image_to_nhwc4_f32(const float* img, float* out, int batch, int h, int w, void* stream);
 /* NHWC [b][h][w][c] -> NCHW [b][c][h][w] (for the reference-layout dict entries) */

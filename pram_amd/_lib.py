@@ -51,7 +51,6 @@ _SIGS = {
     "pram_conv2d_nhwc_x3_planes": (I, [P, I, I, I, I, P, P, F, P, P, P, P, P, P, I, I, I, I, P]),
     "pram_conv3x3_grouped_planes_x3_f32": (I, [P, P, I, I, I, I, P, P, F, P, P, P, I, I, P]),
     "pram_sfd2_conv1_x3_f32": (I, [P, I, I, I, P, P, F, P, P, P, P, P, F, P, P, P, P, I, P]),
-    "pram_resblock_nhwc_x3_f32": (I, [P, I, I, I, P, P, F, P, P, P, P, P, P, P, F, P, P, P, P]),
     "pram_conv2d_nhwc_x3_f32": (I, [P, I, I, I, I, P, P, F, P, P, P, P, P, I, I, I, I, P]),
     "pram_bgemm_nt_x3p_f32": (I, [P, P, I, LL, P, P, I, LL, P, I, LL, I, I, I, I, F, P]),
     "pram_bgemm_nt_f32": (I, [P, I, LL, P, I, LL, P, I, LL, I, I, I, I, F, P]),

@@ -13,6 +13,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the boundary promises the reference's fp32 op order where it is cheap to keep
 # (coordinate maps, rotary, Sinkhorn scaling); hot VALU loops call fmaf explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file additions to FLAGS (measured A/Bs: profiles/r05_*; MI355X_MICROARCH.md: packed fp32 VALU beside MFMAs is an anti-lever)
+FILE_FLAGS: dict[str, list[str]] = {}
+
+
+def flags_for(src: Path) -> list[str]:
+    return FLAGS + FILE_FLAGS.get(src.name, [])
 
 
 def sources():
@@ -38,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *flags_for(src), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -28,7 +28,34 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int D = 64, QW = 32, NW = 4, BQ = QW * NW, BKV = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3::ACT_SCALE)
+// Build knobs of the pipelined kernel's soft-max (profiles/r05_x3_attention_valu_diet.txt has the A/B of each):
+#ifndef AX_SCALAR
+#define AX_SCALAR 0      // 1: scalar fp32 VALU (v_fma_f32 / v_mul_f32) instead of packed (v_pk_*): compile with -fno-slp-vectorize as well
+#endif
+#ifndef AX_MIX
+#define AX_MIX 0         // 1: the probabilities' lo parts by v_fma_mixlo / mixhi_f16
+#endif
+#ifndef AX_SWAP
+#define AX_SWAP 0        // 1: the half-waves exchange their row maxima by v_permlane32_swap instead of ds_bpermute
+#endif
+#ifndef AX_LAZY
+#define AX_LAZY 0        // 1: lazy running maximum (threshold LAZY_T), output accumulators rescaled only when a lane's maximum moved
+#endif
+#ifndef AX_PRIO
+#define AX_PRIO 0        // 1: static s_setprio 1 for waves 4-7 of the eight-wave workgroup
+#endif
+#ifndef AX_VPM
+#define AX_VPM 6         // vector instructions scheduled behind each score MFMA of the interleaved region
+#endif
+#ifndef AX_VPM_HI
+#define AX_VPM_HI 18
+#endif
+#if AX_LAZY
+constexpr float LAZY_T = 8.0f;
+constexpr float P_EXP_SHIFT = 7.0f;     // probabilities carried as 2^7 p, at most 2^15 with the lazy maximum LAZY_T behind
+#else
 constexpr float P_EXP_SHIFT = 14.0f;    // probabilities carried as 2^14 p
+#endif
 
 struct ArgsX {
     const _Float16* qh; const _Float16* ql; const _Float16* kh; const _Float16* kl;
@@ -475,7 +502,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+#if AX_MIX
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    int4v ph[2][2], pl[2][2];          // packed fp16 pairs: register j of ph[t][u] holds the probabilities of score registers 8u + 2j, 8u + 2j + 1
+#else
     half8 ph[2][2], pl[2][2];
+#endif
     // Chunk bookkeeping.  MODE 1 (fused): a running total (o_tot, l_tot2) is folded at every chunk end by the left fold
     // combine_x3_kernel applies; it does not fit beside the two score tiles of the software pipeline (256 registers at two waves
     // per SIMD), the compiler spills and reloads it around the chunk end: +6 % for two 2048-key chunks, +17 % at 512.  MODE 2 (split):
@@ -556,27 +588,97 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             l_tot2 = lse_c;
         }
     };
-    // softmax(S) of one tile: running max / sum, the probabilities as fp16 (and their residuals when PSPLIT), O rescaled
-    auto softmax = [&](f32x16 (&st)[2]) {
+    // O *= alpha.  AX_LAZY: called between the interleaved score / soft-max region and P V, skipped when no lane's maximum moved
+    auto rescale = [&](float alpha) {
+#if AX_LAZY
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) return;
+#endif
+#if AX_SCALAR
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[dn][e] *= alpha;
+#else
+        const f2 al2 = {alpha, alpha};
+#pragma unroll
+        for (int dn = 0; dn < 2; ++dn)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f2 o = (f2){oacc[dn][e], oacc[dn][e + 1]} * al2;
+                oacc[dn][e] = o[0];
+                oacc[dn][e + 1] = o[1];
+            }
+#endif
+    };
+    // softmax(S) of one tile: running max / sum, the probabilities as fp16 (and their residuals when PSPLIT), O rescaled.
+    // Returns alpha, the factor the caller owes the output accumulators (AX_LAZY: applied by rescale() outside the interleaved region).
+    auto softmax = [&](f32x16 (&st)[2]) -> float {
         float tmax = st[0][0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+#if AX_SWAP
+        {   // the other half-wave's maximum by v_permlane32_swap (a vector-ALU move) instead of ds_bpermute (an LDS round trip)
+            float a = tmax, b = tmax;
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+            tmax = fmaxf(a, b);
+        }
+#else
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+#endif
+#if AX_LAZY
+        // the running maximum follows the row maximum only when it is left behind by more than LAZY_T (log2 units): the
+        // probabilities then reach 2^(P_EXP_SHIFT + LAZY_T) at most, alpha is exactly 1 on almost every tile
+        const float t2 = tmax * p.scale2;
+        const float m_new = (t2 > m_run + LAZY_T) ? t2 : m_run;
+#else
         const float m_new = fmaxf(m_run, tmax * p.scale2);
+#endif
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         const float shift = P_EXP_SHIFT - m_new;
-        const f2 sc2 = {p.scale2, p.scale2}, sh2 = {shift, shift}, al2 = {alpha, alpha};
         const half2_t ones = {(_Float16)1.f, (_Float16)1.f};
         float psum = 0.f;
+#if AX_LAZY
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};      // four partial row sums: no 16-deep dependent chain in front of P V
+#endif
+#if AX_SCALAR
+        const float sc = p.scale2;
+#else
+        const f2 sc2 = {p.scale2, p.scale2}, sh2 = {shift, shift};
+#endif
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
+#if AX_SCALAR
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(st[t][e], sc, shift));       // argument <= P_EXP_SHIFT (+ LAZY_T)
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(st[t][e + 1], sc, shift));
+#else
                 const f2 y = __builtin_elementwise_fma((f2){st[t][e], st[t][e + 1]}, sc2, sh2);      // one rounding, like fmaf
                 const float p0 = __builtin_amdgcn_exp2f(y[0]);       // argument <= 14
                 const float p1 = __builtin_amdgcn_exp2f(y[1]);
+#endif
+#if AX_MIX
+                const half2_t pk = __builtin_convertvector((f2){p0, p1}, half2_t);      // v_cvt_pk_f16_f32
+                const int hi2 = __builtin_bit_cast(int, pk);
+                ph[t][e >> 3][(e & 7) >> 1] = hi2;
+                if constexpr (PSPLIT) {
+#if AX_LAZY
+                    ps4[(e >> 1) & 3] += p0 + p1;
+#else
+                    psum += p0 + p1;
+#endif
+                    // lo = fp16(p - hi) in ONE instruction per element (v_fma_mixlo / mixhi_f16: p * 1 - hi with hi read as fp16 from its
+                    // half of the packed register) instead of convert back, subtract, convert: the same value, bit for bit
+                    int lo2;
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(lo2) : "v"(p0), "v"(p1), "v"(hi2));
+                    pl[t][e >> 3][(e & 7) >> 1] = lo2;
+                } else {
+                    psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
+                }
+#else
                 const half2_t pk = {(_Float16)p0, (_Float16)p1};
                 ph[t][e >> 3][e & 7] = pk[0];
                 ph[t][e >> 3][(e & 7) + 1] = pk[1];
@@ -587,29 +689,34 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                 } else {
                     psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
                 }
+#endif
             }
+#if AX_LAZY
+        if constexpr (PSPLIT) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#endif
         l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
-#pragma unroll
-        for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const f2 o = (f2){oacc[dn][e], oacc[dn][e + 1]} * al2;
-                oacc[dn][e] = o[0];
-                oacc[dn][e + 1] = o[1];
-            }
+#if !AX_LAZY
+        rescale(alpha);
+#endif
+        return alpha;
     };
+#if AX_MIX
+#define PB(x) __builtin_bit_cast(half8, x)
+#else
+#define PB(x) (x)
+#endif
     auto vmma = [&](int t, int u, const VFrag& f) {
         if constexpr (!HI) {
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, PB(ph[t][u]), oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, PB(ph[t][u]), oacc[1], 0, 0, 0);
         }
         if constexpr (PSPLIT) {
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(pl[t][u]), oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(pl[t][u]), oacc[1], 0, 0, 0);
         }
-        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ph[t][u], oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ph[t][u], oacc[1], 0, 0, 0);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(ph[t][u]), oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(ph[t][u]), oacc[1], 0, 0, 0);
     };
     auto pv = [&](int vbuf) {
         VFrag va, vb;
@@ -676,21 +783,30 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             kload(kbuf, 3, fb);
             kmma(sn, 2, fa);
             kmma(sn, 3, fb);
-            softmax(sc);
+            const float alpha = softmax(sc);
             // one MFMA, then VALU work of the soft-max in its shadow; the eight fragment reads go out with the first groups
 #pragma unroll
             for (int g = 0; g < (HI ? 8 : 24); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (g < (HI ? 4 : 8)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, HI ? 18 : 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, HI ? AX_VPM_HI : AX_VPM, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if AX_LAZY
+            rescale(alpha);
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            (void)alpha;
+#endif
             pv(vbuf);
         }
         lstore_v((j + 1) & 1);
         if (more_k) lstore_k(j & 1);
         __syncthreads();
     };
+#if AX_PRIO
+    if (NWV == 2 * NW && wave >= NW) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every VALU arbitration otherwise
+#endif
     int j = t0;
     if constexpr (MODE != 0) {
         // Whole key chunks that are followed by at least one more tile: eight tiles (the score-tile ping-pong comes back to
@@ -724,7 +840,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                 for (int e = 0; e < 16; ++e)
                     if (kbase + t * 32 + key_of(e, h) >= klen) sc[t][e] = -INFINITY;
         }
-        softmax(sc);
+        const float alpha = softmax(sc);
+#if AX_LAZY
+        rescale(alpha);
+#else
+        (void)alpha;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         pv((nkt - 1) & 1);
     };
@@ -1077,8 +1198,13 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
             scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift, IN_SCALE, 1, 0, chunk_tiles(), nullptr, nullptr};
+#ifdef PRAM_PROFILING      // the non-pipelined kernel and its ablations (garbage results, PRAM_OK): profiling builds only
     static const char* abl = getenv("PRAM_ATTN_ABLATE");
     static const char* v1 = getenv("PRAM_ATTN_V1");
+#else
+    constexpr const char* abl = nullptr;
+    constexpr const char* v1 = nullptr;
+#endif
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (!(v1 && v1[0] == '1') && !abl) {
@@ -1127,6 +1253,7 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
         hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
     }
+#ifdef PRAM_PROFILING
     // PRAM_ATTN_V1 / PRAM_ATTN_ABLATE (profiling): the non-pipelined kernel — one online soft-max over all keys, so its results
     // differ from the chunked default in the last bits
     if (n_max < 1024) {
@@ -1141,6 +1268,7 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
         case 8: hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p); break;
         default: hipLaunchKernelGGL((attention_x3_kernel<0, false>), grid, blk, 0, st, p);
     }
+#endif
     return pram_launch_status("pram_attention_x3_f32");
 }
 

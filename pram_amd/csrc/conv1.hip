@@ -261,7 +261,11 @@ extern "C" int pram_sfd2_conv1_x3_f32(const float* img, int batch, int h, int w,
     c1::Args p{img, out, (const _Float16*)wa_hi, (const _Float16*)wa_lo, 1.0f / (gemmx3::ACT_SCALE * wa_scale), ba, sa, ta,
                (const _Float16*)wb_hi, (const _Float16*)wb_lo, 1.0f / (gemmx3::ACT_SCALE * wb_scale), bb, sb, tb,
                batch, h, w, ho, wo, cdiv(wo, c1::TW), cdiv(ho, c1::TH), pram_status_ptr(), 0, img_nchw3 != 0};
+#ifdef PRAM_PROFILING      // ablations return garbage: compiled into profiling builds only (profiles/tools/build_variants.py ...:-DPRAM_PROFILING)
     { const char* e = getenv("PRAM_C1_ABLATE"); p.abl = e ? atoi(e) : 0; }
+#else
+    p.abl = 0;
+#endif
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv1ab_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c1::SMEM_BYTES);

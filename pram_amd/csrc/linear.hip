@@ -837,6 +837,7 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
             return;
         }
     }
+#ifdef PRAM_PROFILING      // ablations (garbage results, PRAM_OK): profiling builds only (build_variants.py TAG:linear.hip:-DPRAM_PROFILING)
     static const char* abl = getenv("PRAM_GEMM_ABLATE");
     const int ab = abl ? atoi(abl) : 0;
     if (ab == 0) { hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, batch), dim3(C::NT), shm, st, p, a, wh, wl, inv); return; }
@@ -851,6 +852,9 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
     else if (ab == 16) go(linear_x3w_kernel<MI, WM, WN, APLANES, 16>);    // no A staging
     else if (ab == 32) go(linear_x3w_kernel<MI, WM, WN, APLANES, 32>);    // no B DMA
     else go(linear_x3w_kernel<MI, WM, WN, APLANES, 3>);
+#else
+    hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, batch), dim3(C::NT), shm, st, p, a, wh, wl, inv);
+#endif
 }
 
 // wide tiles (gemm_core_x3w.h) for outputs at least 256 columns wide: 256 x 256 when that still gives every CU a workgroup,

@@ -16,10 +16,6 @@ from .. import ops
 from . import _blocks as blk
 
 import os as _os
-# conv4's ResBlocks as ONE kernel each on the split-fp16 path (pram_resblock_nhwc_x3_f32: bit-identical to the three kernels it replaces).
-# Opt-in: in its first form the fused kernel is no faster (758 vs 735 us per block at the bench shape, profiles/r04_resblock_probe.txt):
-# with one 133 KB workgroup per CU nothing overlaps its own HBM streaming (DESIGN.md 4.12 has the anatomy and what it would take).
-FUSED_RES = _os.environ.get("PRAM_FUSED_RES", "0") == "1"
 # conv1a -> conv1b as one kernel on the split-fp16 path (pram_sfd2_conv1_x3_f32); 0: two kernels (conv1a on the exact-fp32 MFMA kernel)
 FUSED_CONV1 = _os.environ.get("PRAM_FUSED_CONV1", "1") != "0"
 
@@ -130,11 +126,6 @@ class ResNet4x(blk.PackedCache, nn.Module):
         o4 = o3b
         for i in range(3):
             p = f"conv4.{i}"
-            if FUSED_RES and ops.gemm_prec() == "x3" and o4.shape[-1] == 256:
-                # the whole block in one kernel: the two intermediate maps never leave the CU (bit-identical to the three ops below)
-                o4 = ops.resblock_nhwc(o4, P[p + ".w1"], P[p + ".s1"], P[p + ".t1"], P[p + ".w2"], P[p + ".s2"], P[p + ".t2"],
-                                       P[p + ".w3"], P[p + ".s3"], P[p + ".t3"])
-                continue
             if ops.GROUPED_X3 and ops.gemm_prec() == "x3" and o4.shape[-1] % 64 == 0 and o4.numel() < (1 << 29):      # (32-bit buffer offsets)
                 # the 1x1 hands its result over as split fp16 planes; the grouped 3x3 runs on the matrix pipe from them
                 yh, yl = ops.conv2d_nhwc_planes(o4, P[p + ".w1"], None, P[p + ".s1"], P[p + ".t1"], ks=1, relu=True)

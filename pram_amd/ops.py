@@ -465,6 +465,12 @@ def _mark_x3(device) -> None:
     _x3_counts[i] = _x3_counts.get(i, 0) + 1
 
 
+def mark_x3(device) -> None:
+    """For callers that re-issue captured work (hipGraph replays launch nothing through these bindings): arm the range guard's
+    read for ``device`` without counting a launch — x3_launched() is True again until the status word is next read."""
+    _x3_pending.add(_dev_index(device))
+
+
 def x3_launch_count(device=None) -> int:
     """Split-fp16 launches issued (or captured) on ``device`` so far: a caller that replays captured work compares the count
     around the capture to know whether its replays can set the status word."""
@@ -1047,21 +1053,6 @@ def conv3x3_grouped_planes(hi: torch.Tensor, lo: torch.Tensor, w: torch.Tensor, 
     wh, wl, ws = split_weight(w)
     _lib.check(L.pram_conv3x3_grouped_planes_x3_f32(_p(hi), _p(lo), B, H, W, Cc, _p(wh), _p(wl), ws, _p(scale), _p(shift), _p(out),
                                                     groups, int(relu), _st()), "pram_conv3x3_grouped_planes_x3_f32")
-    return out
-
-
-def resblock_nhwc(x: torch.Tensor, w1: torch.Tensor, s1, t1, w2: torch.Tensor, s2, t2, w3: torch.Tensor, s3, t3) -> torch.Tensor:
-    """One SFD2 ResBlock (nets/sfd2.py:107-124) on the split-fp16 path as ONE kernel (pram_resblock_nhwc_x3_f32): x NHWC fp32
-    [B, H, W, 256]; w1 / w3 the 1x1 weights as conv2d_nhwc takes them ([256, 1, 1, 256] or [256, 256]), w2 the grouped 3x3 weights
-    as conv3x3_grouped_nhwc takes them; s / t = folded BatchNorm.  Bit-identical to the three ops it replaces."""
-    L = _lib.load()
-    assert x.is_contiguous() and x.shape[-1] == 256 and w2.is_contiguous()
-    B, H, W, _ = x.shape
-    out = torch.empty_like(x)
-    w1h, w1l, ws1 = split_weight(w1)
-    w3h, w3l, ws3 = split_weight(w3)
-    _lib.check(L.pram_resblock_nhwc_x3_f32(_p(x), B, H, W, _p(w1h), _p(w1l), ws1, _p(s1), _p(t1), _p(w2), _p(s2), _p(t2),
-                                           _p(w3h), _p(w3l), ws3, _p(s3), _p(t3), _p(out), _st()), "pram_resblock_nhwc_x3_f32")
     return out
 
 

@@ -227,6 +227,8 @@ class GraphedPipeline:
         self.out = out
 
     def _replay(self):
+        if self.uses_x3:
+            ops.mark_x3(self.images.device)      # replays launch nothing through the bindings: arm the range guard's read here
         if not self.split:
             self.graph.replay()
             return
@@ -277,15 +279,17 @@ class GraphedPipeline:
             if guard == "raise":
                 from ._lib import PramHipError
                 raise PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 in the replayed step")
-            # The captured buffers (self.out, self.record) now hold the overflowed replay: the result of THIS call is the eager
-            # exact-fp32 re-run returned below, and self.record follows it (fresh tensors, not the captured ones) so that a caller
-            # reading g.record after run() never sees the NaN-derived record.  The re-run cannot overflow (no split kernels under
-            # forced_precision), hence "deferred".  One status word serves the whole device: a caller that keeps OTHER replays in
-            # flight on other streams must use replay() and check ops.x3_range_exceeded() itself once they are done — the reset
-            # here is not ordered against them.
+            # The captured buffers (self.out, self.record) hold the overflowed replay: the result of THIS call is the eager exact-fp32
+            # re-run returned below.  The re-run gets the CAPTURED inputs (self.images / self.ref were just refreshed from the
+            # arguments: `ref=None` means "the captured reference sets", not "no matcher"), and its record is copied INTO the
+            # captured record tensor — self.record stays the buffer every later replay writes, so a caller that keeps reading
+            # g.record after replay() sees that replay's record, not this call's.  The re-run cannot overflow (no
+            # split kernels under forced_precision), hence "deferred".  One status word serves the whole device: a caller that
+            # keeps OTHER replays in flight on other streams must use replay() and check ops.x3_range_exceeded() itself once they
+            # are done — the reset here is not ordered against them.
             with ops.forced_precision("f32"):
-                out = self.pipe.run(images, ref, self.stages, guard="deferred")
+                out = self.pipe.run(self.images, self.ref, self.stages, guard="deferred")
                 if self.with_record:
-                    self.record = QueryPipeline.pack_record(out)
+                    self.record.copy_(QueryPipeline.pack_record(out))
             return out
         return self.out

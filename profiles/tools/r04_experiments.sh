@@ -22,5 +22,6 @@ if [ $what = attnsweep ] || [ $what = all ]; then  # profiles/r04_x3_attention_b
   PRAM_PROBE_SHAPES=8x2048,16x2048,24x2048,32x2048,48x2048,64x2048,16x1024,32x1024,64x1024,4x4096,8x4096,16x4096 python profiles/tools/x3_attn_probe.py 2>&1 | grep -v amdgpu
 fi
 if [ $what = resblock ] || [ $what = all ]; then   # profiles/r04_resblock_probe.txt
-  for a in 0 1 2 4 7; do PRAM_RB_ABLATE=$a python profiles/tools/resblock_probe.py 2>&1 | grep "B=" | sed "s/^/abl=$a /"; done
+  for a in 0 1 2 4 7; do PRAM_RB_ABLATE=$a python profiles/experiments/resblock_probe_r04.py  # (needs the round-4 tree: the fused ResBlock kernel left the library in round 5)
+  2>&1 | grep "B=" | sed "s/^/abl=$a /"; done
 fi

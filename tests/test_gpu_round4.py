@@ -174,62 +174,22 @@ def test_sinkhorn_on_non_finite_scores_never_faults(dev):
             assert int(r["matches0"][1].max()) < n and int(r["matches1"][1].max()) < m
 
 
-def _resblock_params(dev, seed=3):
-    """One ResBlock's packed parameters the way ResNet4x._build_packed makes them (random, ReLU-friendly)."""
-    P = {}
-    P["w1"] = W.normal(seed, "rb/w1", (256, 1, 1, 256), 0.08).to(dev)
-    P["w2"] = W.normal(seed, "rb/w2", (256, 3, 3, 8), 0.15).to(dev)
-    P["w3"] = W.normal(seed, "rb/w3", (256, 1, 1, 256), 0.08).to(dev)
-    for j in (1, 2, 3):
-        P[f"s{j}"] = W.uniform(seed, f"rb/s{j}", (256,), 0.6, 1.4).to(dev)
-        P[f"t{j}"] = W.normal(seed, f"rb/t{j}", (256,), 0.2).to(dev)
-    return P
-
-
-def _resblock_three(x, P):
-    y = ops.conv2d_nhwc(x, P["w1"], None, P["s1"], P["t1"], ks=1, relu=True, precision="x3")
-    y = ops.conv3x3_grouped_nhwc(y, P["w2"], P["s2"], P["t2"], groups=32, relu=True)
-    return ops.conv2d_nhwc(y, P["w3"], None, P["s3"], P["t3"], residual=x, ks=1, relu=True, precision="x3")
-
-
-@pytest.mark.parametrize("shape", [(2, 24, 32), (1, 8, 16), (3, 21, 37), (1, 5, 3), (2, 120, 160)])
-def test_fused_resblock_equals_three_kernels(dev, shape):
-    """pram_resblock_nhwc_x3_f32 = 1x1 -> grouped 3x3 -> 1x1 + identity, bit for bit (tile-aligned frames, ragged ones, a frame
-    smaller than a tile, the bench's 120 x 160 maps), and it reports a value beyond the split format's range like its parts do."""
-    B, Hh, Ww = shape
-    P = _resblock_params(dev)
-    x = torch.relu(W.normal(9, f"rb/x{shape}", (B, Hh, Ww, 256), 1.0)).to(dev).contiguous()
-    ops.x3_range_exceeded(dev)
-    want = _resblock_three(x, P)
-    got = ops.resblock_nhwc(x, P["w1"], P["s1"], P["t1"], P["w2"], P["s2"], P["t2"], P["w3"], P["s3"], P["t3"])
-    assert not ops.x3_range_exceeded(dev)
-    assert bool(torch.isfinite(got).all())
-    assert torch.equal(got, want), float((got - want).abs().max())
-    if shape == (2, 24, 32):
-        xb = x.clone()
-        xb[1, 7, 9, 100] = 5.0e3
-        ops.resblock_nhwc(xb, P["w1"], P["s1"], P["t1"], P["w2"], P["s2"], P["t2"], P["w3"], P["s3"], P["t3"])
-        assert ops.x3_range_exceeded(dev)
-
-
-def test_sfd2_backbone_with_fused_resblocks_is_bit_identical(dev):
+def test_sfd2_backbone_grouped_matrix_pipe_is_fp32_class(dev):
+    """conv4's ResBlocks: 1x1 -> planes -> grouped 3x3 on the matrix pipe (the default) against the vector kernel's exact-fp32
+    grouped 3x3 (nets/sfd2.py:107-124)."""
     from pram_amd.nets import sfd2 as S
     net = S.ResNet4x()
     net.load_state_dict(H.sfd2_sd(), strict=True)
     net = net.to(dev).eval()
     img = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)]).to(dev)
-    saved, saved_g = S.FUSED_RES, ops.GROUPED_X3
+    saved_g = ops.GROUPED_X3
     try:
-        S.FUSED_RES = True
-        a = net._backbone(img)[-1]
-        S.FUSED_RES = False
-        ops.GROUPED_X3 = False      # the fused block carries the exact-fp32 grouped 3x3 of the vector kernel
+        ops.GROUPED_X3 = False
         b = net._backbone(img)[-1]
-        ops.GROUPED_X3 = True       # the default: 1x1 -> planes -> grouped 3x3 on the matrix pipe (fp32-class, not the same bits)
+        ops.GROUPED_X3 = True
         c = net._backbone(img)[-1]
     finally:
-        S.FUSED_RES, ops.GROUPED_X3 = saved, saved_g
-    assert torch.equal(a, b)
+        ops.GROUPED_X3 = saved_g
     assert float((c - b).abs().max()) <= 4e-6 * float(b.abs().max())
 
 
