@@ -576,6 +576,12 @@ int pram_linear_f16_lngelu_f32(const void* hidden16, int ldh, int k, const void*
 int pram_pack_record_f32(const float* kpts, const float* scores, const int* landmark, const long long* matches0,
                          const float* mscores0, int batch, int k, int km, float* rec, void* stream);
 
+/* Frame staging — replaces, per query frame, `torch.from_numpy(img / 255).permute(2, 0, 1).cuda().float()` followed by
+ * `tvf.Normalize(mean, std)` (localization/loc_by_rec_online.py:98-106, nets/sfd2.py:14-17): frames_hwc3 = uint8 [batch][h][w][3] as
+ * cv2.imread delivers them (channel order untouched, like the reference), lut = fp32 [3][256] with lut[c][v] = ((v / 255) - mean[c]) /
+ * std[c] computed by the caller with the reference's own operations, out = fp32 [batch][3][h][w].  h * w a multiple of 4. */
+int pram_stage_frames_u8(const void* frames_hwc3, const float* lut, float* out_nchw, int batch, int h, int w, void* stream);
+
 /* dst[0 .. count) <- value, 32-bit words, on the stream (torch.zeros / torch.full of the host-side glue without a framework kernel). */
 int pram_fill_u32(void* dst, unsigned int value, size_t count, void* stream);
 

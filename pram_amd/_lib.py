@@ -98,6 +98,7 @@ _SIGS = {
     "pram_linear_f16_lngelu_f32": (I, [P, I, I, P, P, P, I, P, I, I, I, P, I, P, P, F, P]),
     "pram_pack_record_f32": (I, [P, P, P, P, P, I, I, I, P, P]),
     "pram_fill_u32": (I, [P, C.c_uint, SZ, P]),
+    "pram_stage_frames_u8": (I, [P, P, P, I, I, I, P]),
     "pram_score_lookup_f32": (I, [P, LL, I, I, P, P, I, I, P, P]),
 }
 

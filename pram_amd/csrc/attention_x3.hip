@@ -41,6 +41,28 @@ constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3
 #ifndef AX_LAZY
 #define AX_LAZY 0        // 1: lazy running maximum (threshold LAZY_T), output accumulators rescaled only when a lane's maximum moved
 #endif
+#ifndef AX_SPREAD
+#define AX_SPREAD 0      // 1: the soft-max arithmetic spread over BOTH matrix phases of a tile (implies SCALAR, MIX, SWAP, LAZY) — see softmax_a / pv_b
+#endif
+#if AX_SPREAD
+#undef AX_SCALAR
+#undef AX_MIX
+#undef AX_SWAP
+#undef AX_LAZY
+#define AX_SCALAR 1
+#define AX_MIX 1
+#define AX_SWAP 1
+#define AX_LAZY 1
+#endif
+#ifndef AX_VPA
+#define AX_VPA 4         // AX_SPREAD: vector instructions behind each score MFMA (phase A) ...
+#endif
+#ifndef AX_VPB
+#define AX_VPB 4         // ... and behind each P V MFMA (phase B)
+#endif
+#ifndef AX_MAXG
+#define AX_MAXG 7        // AX_SPREAD: leading MFMA groups of phase A that carry the row maximum (4 vector instructions each)
+#endif
 #ifndef AX_PRIO
 #define AX_PRIO 0        // 1: static s_setprio 1 for waves 4-7 of the eight-wave workgroup
 #endif
@@ -371,8 +393,18 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
 // NWV: waves per workgroup.  Four (128 query rows, two workgroups per CU) everywhere but on full grids of MODE 0, where eight
 // (256 rows, one workgroup per CU: the same 64 KB of LDS, the same registers per wave) stage every K / V tile once per 256 query
 // rows instead of once per 128 — the staging is what the tile loop pays for beside its MFMAs (profiles/r02_x3_attention_ablation.txt).
+#ifdef PRAM_PROFILING
+// per-workgroup timeline of the last launch (profiles/tools/x3_attn_timeline.py): [blockIdx.x][0] start, [1] end (100 MHz wall
+// clock), [2] XCC id << 16 | HW_ID bits, [3] shader clocks spent
+static __device__ unsigned long long attn_prof[4096][4];
+static __device__ unsigned long long attn_phase[8][4];      // per wave of the workgroup: shader clocks per tile phase, summed over workgroups
+#endif
+
 template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW>
 __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe_kernel(ArgsX p) {
+#ifdef PRAM_PROFILING
+    const unsigned long long prof_t0 = wall_clock64(), prof_c0 = __builtin_readcyclecounter();
+#endif
     constexpr int BQV = QW * NWV;            // query rows of the workgroup
     constexpr int SROWS = NWV * 8;           // K rows / V^T rows one staging pass of the workgroup covers (8 threads per row)
     constexpr int PPN = BKV / SROWS;         // staging passes per tile
@@ -380,6 +412,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     __shared__ typename SmemSel<HI>::type s;
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    float one = 1.0f;      // a 1.0 the optimiser cannot see through (quarter(): keeps fma(p, 1, -hi) an fma)
+    asm volatile("" : "+s"(one));
     const int nblk = p.batch * p.heads * p.q_tiles;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int qt = id % p.q_tiles;
@@ -734,6 +768,102 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         vmma(1, 1, vb);
     };
 
+
+#if AX_SPREAD
+    // The vector ALU is the second bound of this kernel (profiles/r05_mfma_valu_overlap.txt: beside one v_mfma_f32_32x32x16_f16 =
+    // 33.5 clocks a wave hides ~23 clocks of vector issue — a VOP2 costs 4, a VOP3 5, v_exp_f32 and v_fma_mix 8 — and the two waves
+    // of a SIMD share the issue port).  One tile's soft-max is ~1 000 such clocks; bunched behind the 24 score MFMAs (42 per MFMA)
+    // it made that phase issue-bound and left the 24 P V MFMAs bare (profiles/r05_attn_phases.txt: the younger wave of every SIMD
+    // needed 3 760 clocks for the phase, the older one waited 1 900 at the barrier).  Here it is split where the data allows:
+    //   part A (beside S_{j+1} = K_{j+1} Q^T): row maximum, p = 2^(s c + shift) left in place of the scores       ~22 clocks per MFMA
+    //   part B (beside O += V_j P_j): per 16-key quarter, right in front of the MFMAs that take them: fp16 hi parts
+    //          (v_cvt_pk), lo parts (v_fma_mix), row sums                                                          ~19 clocks per MFMA
+    auto softmax_a = [&](f32x16 (&st)[2]) -> float {
+        float tmax = st[0][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
+        {
+            float a = tmax, b = tmax;
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+            tmax = fmaxf(a, b);
+        }
+        const float t2 = tmax * p.scale2;
+        const float m_new = (t2 > m_run + LAZY_T) ? t2 : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float shift = P_EXP_SHIFT - m_new;
+        const float sc = p.scale2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[t][e] = __builtin_amdgcn_exp2f(fmaf(st[t][e], sc, shift));      // argument <= P_EXP_SHIFT + LAZY_T
+        m_run = m_new;
+        return alpha;
+    };
+    // the fp16 hi parts of one 16-key quarter (four v_cvt_pk_f16_f32; the single-product mode sums the rounded values here)
+    auto hi_parts = [&](int t, int u, f32x16 (&st)[2], float& psum) -> int4v {
+        int4v hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const half2_t pk = __builtin_convertvector((f2){st[t][8 * u + 2 * j], st[t][8 * u + 2 * j + 1]}, half2_t);
+            hi[j] = __builtin_bit_cast(int, pk);
+            if constexpr (!PSPLIT) psum = __builtin_amdgcn_fdot2(pk, (half2_t){(_Float16)1.f, (_Float16)1.f}, psum, false);
+        }
+        return hi;
+    };
+    // part B + P V of one tile, written in the order it is meant to issue (the sched_group_barriers behind the call pin it): per
+    // 16-key quarter the four products that take P_hi, each followed by one element pair's lo parts (v_fma_mixlo / mixhi) and its
+    // sum; then the two products that take P_lo, followed by the row-sum updates and the NEXT quarter's hi parts.
+    // va / vb: the V^T fragments of the first two quarters, already requested.
+    auto pv_b = [&](int vbuf, f32x16 (&st)[2], float alpha, VFrag& va, VFrag& vb) {
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f}, psum = 0.f;
+        int4v hi = hi_parts(0, 0, st, psum);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int t = qd >> 1, u = qd & 1;
+            VFrag& f = u ? vb : va;
+            int4v lo;
+            float pair[4];
+            auto lo_pair = [&](int j) {
+                if constexpr (PSPLIT) {
+                    const float p0 = st[t][8 * u + 2 * j], p1 = st[t][8 * u + 2 * j + 1];
+                    // lo = fp16(p - hi) as ONE instruction per element: fma(p, 1, -hi) with the 1 hidden from the optimiser selects
+                    // v_fma_mixlo / mixhi_f16 (hi read as fp16 from its half of the packed register); a plain p - (float)hi would be
+                    // convert, subtract, convert.  Same value bit for bit (the difference is exact in fp32).
+                    const half2_t hk = __builtin_bit_cast(half2_t, hi[j]);
+                    const half2_t lk = {(_Float16)__builtin_fmaf(p0, one, -(float)hk[0]), (_Float16)__builtin_fmaf(p1, one, -(float)hk[1])};
+                    lo[j] = __builtin_bit_cast(int, lk);
+                    pair[j] = p0 + p1;
+                }
+            };
+            if constexpr (!HI) {
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, PB(hi), oacc[0], 0, 0, 0);
+                lo_pair(0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, PB(hi), oacc[1], 0, 0, 0);
+                lo_pair(1);
+            }
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(hi), oacc[0], 0, 0, 0);
+            lo_pair(2);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(hi), oacc[1], 0, 0, 0);
+            lo_pair(3);
+            int4v nhi = hi;
+            if (qd < 3) nhi = hi_parts((qd + 1) >> 1, (qd + 1) & 1, st, psum);
+            if constexpr (PSPLIT) {
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(lo), oacc[0], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ps4[j] += pair[j];
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(lo), oacc[1], 0, 0, 0);
+            }
+            hi = nhi;
+            if (qd == 0) vload(vbuf, 1, 0, va);       // this quarter is through with va / vb: the fragments of quarter qd + 2
+            if (qd == 1) vload(vbuf, 1, 1, vb);
+        }
+        if constexpr (PSPLIT) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        l_run = fmaf(l_run, alpha, psum);
+    };
+#endif
+
     // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own  (tile numbers relative to t0, which is even: the
     // stage parity of a tile is that of its absolute number)
     gload_k(t0);
@@ -764,12 +894,89 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     // reading K_0 first
     if (t0 + 2 < nkt) __syncthreads();
 
+#ifdef PRAM_PROFILING
+    // shader clocks per phase of a tile, summed over the tile loop: [0] loads issued + scores of tile j+1 interleaved with the
+    // soft-max of tile j, [1] P V, [2] the staged tiles written to LDS (waits for the loads), [3] barrier
+    unsigned long long prof_ts[5] = {0, 0, 0, 0, 0}, prof_ph[4] = {0, 0, 0, 0};
+#define PROF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); prof_ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROF_STAMP(i) do { } while (0)
+#endif
     // tile j (not the last): S_{j+1} = K_{j+1} Q^T interleaved with softmax(S_j), then O += V_j P_j; K_{j+2} and V_{j+1} staged
     auto mid = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
         const int kbuf = (j + 1) & 1, vbuf = j & 1;
         const bool more_k = j + 2 < nkt;
+        PROF_STAMP(0);
         gload_v(j + 1);
         if (more_k) gload_k(j + 2);
+#if AX_SPREAD
+        if (wave_active) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
+            KFrag fa, fb;
+            VFrag va, vb;
+            kload(kbuf, 0, fa);
+            kload(kbuf, 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sn, 0, fa);
+            kload(kbuf, 2, fa);
+            kmma(sn, 1, fb);
+            kload(kbuf, 3, fb);
+            kmma(sn, 2, fa);
+            kmma(sn, 3, fb);
+            vload(vbuf, 0, 0, va);           // the first two quarters' V^T fragments travel under the end of phase A
+            vload(vbuf, 0, 1, vb);
+            const float alpha = softmax_a(sc);
+            // (the probabilities are only used behind the rescale branch: without a use in THIS block the compiler sinks the 32
+            // v_fma / v_exp pairs below it, out of the MFMAs' shadow)
+            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+            // phase A: one score MFMA, then vector work of part A in its shadow: the row maximum first (everything else waits for
+            // it), then v_fma + v_exp pairs; the fragment reads go out with the first groups (K of the later k-steps, then V^T of
+            // the first quarters).  0x008 MFMA, 0x100 LDS read, 0x002 vector ALU, 0x400 transcendental.
+#pragma unroll
+            for (int g = 0; g < (HI ? 8 : 24); ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < (HI ? 8 : 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (g < (HI ? 2 : AX_MAXG)) __builtin_amdgcn_sched_group_barrier(0x002, HI ? 16 : 4, 0);
+                else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, HI ? 6 : 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, HI ? 6 : 2, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PROF_STAMP(1);
+            rescale(alpha);
+            __builtin_amdgcn_sched_barrier(0);
+            pv_b(vbuf, sc, alpha, va, vb);
+            // phase B as pv_b writes it: 4 v_cvt_pk in front, then per quarter 4 x { MFMA, v_fma_mixlo, v_fma_mixhi, v_add },
+            // { MFMA, the next quarter's 4 v_cvt_pk }, { MFMA, 4 v_add }; the two reloads of the fragment registers behind them
+            __builtin_amdgcn_sched_group_barrier(0x002, HI ? 8 : 4, 0);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                if constexpr (HI) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, PSPLIT ? 3 : 1, 0);
+                    }
+                    if constexpr (PSPLIT) {
+                        if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                }
+                if (qd < 2) __builtin_amdgcn_sched_group_barrier(0x100, HI ? 2 : 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PROF_STAMP(2);
+        }
+#else
         if (wave_active) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
@@ -792,6 +999,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                 __builtin_amdgcn_sched_group_barrier(0x002, HI ? AX_VPM_HI : AX_VPM, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            PROF_STAMP(1);
 #if AX_LAZY
             rescale(alpha);
             __builtin_amdgcn_sched_barrier(0);
@@ -799,10 +1007,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             (void)alpha;
 #endif
             pv(vbuf);
+            PROF_STAMP(2);
         }
+#endif
         lstore_v((j + 1) & 1);
         if (more_k) lstore_k(j & 1);
+        PROF_STAMP(3);
         __syncthreads();
+        PROF_STAMP(4);
+#ifdef PRAM_PROFILING
+        prof_ph[0] += prof_ts[1] - prof_ts[0]; prof_ph[1] += prof_ts[2] - prof_ts[1];
+        prof_ph[2] += prof_ts[3] - prof_ts[2]; prof_ph[3] += prof_ts[4] - prof_ts[3];
+#endif
     };
 #if AX_PRIO
     if (NWV == 2 * NW && wave >= NW) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every VALU arbitration otherwise
@@ -840,6 +1056,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                 for (int e = 0; e < 16; ++e)
                     if (kbase + t * 32 + key_of(e, h) >= klen) sc[t][e] = -INFINITY;
         }
+#if AX_SPREAD
+        VFrag va, vb;
+        vload((nkt - 1) & 1, 0, 0, va);
+        vload((nkt - 1) & 1, 0, 1, vb);
+        const float alpha = softmax_a(sc);
+        rescale(alpha);
+        __builtin_amdgcn_sched_barrier(0);
+        pv_b((nkt - 1) & 1, sc, alpha, va, vb);
+#else
         const float alpha = softmax(sc);
 #if AX_LAZY
         rescale(alpha);
@@ -848,9 +1073,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
 #endif
         __builtin_amdgcn_sched_barrier(0);
         pv((nkt - 1) & 1);
+#endif
     };
     if (in_a) last(sa); else last(sb);
     finish();
+#ifdef PRAM_PROFILING
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        attn_prof[blockIdx.x][0] = prof_t0;
+        attn_prof[blockIdx.x][1] = wall_clock64();
+        attn_prof[blockIdx.x][2] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        attn_prof[blockIdx.x][3] = __builtin_readcyclecounter() - prof_c0;
+    }
+    if (lane == 0 && blockIdx.y == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&attn_phase[wave & 7][i], prof_ph[i]);
+#endif
 
     if (q_ok) {
         const size_t row = (size_t)b * p.m_max + qrow;
@@ -1178,6 +1417,23 @@ extern "C" int pram_attention_x3_set_p_split(int split) {
     if (split >= 0) g_p_split = split ? 1 : 0;
     return p_split_always() ? 1 : 0;
 }
+
+#ifdef PRAM_PROFILING
+/* profiling builds only: the per-workgroup timeline of the last pipelined launch (4096 x 4 uint64, see attn_prof) */
+extern "C" int pram_debug_attention_timeline(unsigned long long* out16384) {
+    if (hipMemcpyFromSymbol(out16384, HIP_SYMBOL(attn_prof), sizeof(unsigned long long) * 4096 * 4) != hipSuccess) return pram_launch_status("pram_debug_attention_timeline");
+    return PRAM_OK;
+}
+/* ... and the per-wave phase clocks (8 x 4 uint64, see attn_phase), summed since the last reset */
+extern "C" int pram_debug_attention_phases(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(attn_phase), sizeof(unsigned long long) * 32) != hipSuccess) return pram_launch_status("pram_debug_attention_phases");
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(attn_phase), z, sizeof(z)) != hipSuccess) return pram_launch_status("pram_debug_attention_phases");
+    }
+    return PRAM_OK;
+}
+#endif
 
 extern "C" int pram_attention_x3_mfma_per_tile(int n_max) { return (n_max < 1024 || p_split_always()) ? 48 : 40; }
 

@@ -465,6 +465,44 @@ extern "C" int pram_pack_record_f32(const float* kpts, const float* scores, cons
     return pram_launch_status("pram_pack_record_f32");
 }
 
+// ---------------------------------------------------------------- frame staging (localization/loc_by_rec_online.py:86-106)
+// The reference prepares a query frame on the host and device in three steps: img / 255 (numpy, float64), .cuda().float(), and
+// tvf.Normalize(mean, std) = sub_(mean).div_(std) per channel of the HWC -> CHW permuted tensor (channels stay in cv2's order).  All
+// three are functions of one byte and the channel, so the device side is a table lookup: lut[c][v] is built ON THE HOST with the
+// reference's own operations (ops.frame_lut), the kernel only moves data — uint8 [b][h][w][3] in, fp32 [b][3][h][w] out: 3 B read
+// and 12 B written per pixel.  One thread = 4 consecutive pixels of a row (12 bytes in as three dwords, one float4 per channel out).
+__global__ __launch_bounds__(256) void stage_frames_kernel(const uint8_t* __restrict__ in, const float* __restrict__ lut,
+                                                            float* __restrict__ out, long long hw, long long quads) {
+    __shared__ float sl[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) sl[i] = lut[i];
+    __syncthreads();
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // (frame, quad of pixels)
+    if (q >= quads) return;
+    const long long per = hw / 4;
+    const long long b = q / per, p0 = (q - b * per) * 4;
+    const unsigned* src = reinterpret_cast<const unsigned*>(in + (b * hw + p0) * 3);
+    const unsigned w0 = src[0], w1 = src[1], w2 = src[2];
+    unsigned char v[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = (w0 >> (8 * i)) & 0xff; v[4 + i] = (w1 >> (8 * i)) & 0xff; v[8 + i] = (w2 >> (8 * i)) & 0xff; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 o = make_float4(sl[c * 256 + v[c]], sl[c * 256 + v[3 + c]], sl[c * 256 + v[6 + c]], sl[c * 256 + v[9 + c]]);
+        *reinterpret_cast<float4*>(out + (b * 3 + c) * hw + p0) = o;
+    }
+}
+
+extern "C" int pram_stage_frames_u8(const void* frames_hwc3, const float* lut, float* out_nchw, int batch, int h, int w, void* stream) {
+    PRAM_REQUIRE(frames_hwc3 && lut && out_nchw, "pram_stage_frames_u8: null pointer");
+    PRAM_REQUIRE(batch >= 0 && h > 0 && w > 0 && ((long long)h * w) % 4 == 0, "pram_stage_frames_u8: h * w must be a multiple of 4");
+    PRAM_REQUIRE(((size_t)frames_hwc3 & 3) == 0 && ((size_t)out_nchw & 15) == 0, "pram_stage_frames_u8: frames 4-byte aligned, output 16-byte aligned");
+    if (batch == 0) return PRAM_OK;
+    const long long hw = (long long)h * w, quads = (long long)batch * hw / 4;
+    hipLaunchKernelGGL(stage_frames_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)frames_hwc3, lut, out_nchw, hw, quads);
+    return pram_launch_status("pram_stage_frames_u8");
+}
+
 /* count 32-bit words at dst <- value (hipMemsetD32Async on the stream): the "zeros / full" initialisations of the host-side
    glue without a framework kernel. */
 extern "C" int pram_fill_u32(void* dst, unsigned int value, size_t count, void* stream) {

@@ -1293,6 +1293,30 @@ def seg_vote(sorted_vals: torch.Tensor, sorted_ids: torch.Tensor, topk: int):
     return sid, rank, cnt, nwin, tokens, mean
 
 
+def frame_lut(mean, std, device) -> torch.Tensor:
+    """[3, 256] fp32: what the reference's frame preparation makes of byte v in channel c — `img / 255` in float64 (numpy),
+    `.float()`, then tvf.Normalize's `sub_(mean).div_(std)` in fp32 (localization/loc_by_rec_online.py:98-106) — computed with exactly
+    those operations, on the host."""
+    v = (torch.arange(256, dtype=torch.float64) / 255).float()[None].repeat(3, 1)
+    m = torch.tensor(mean, dtype=torch.float32).view(3, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(3, 1)
+    return v.sub_(m).div_(s).contiguous().to(device)
+
+
+def stage_frames(frames_u8: torch.Tensor, lut: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 [B, H, W, 3] (cv2 layout, on the device) -> normalised fp32 [B, 3, H, W] (pram_stage_frames_u8): the device half of the
+    reference's per-frame preparation; `lut` from frame_lut()."""
+    L = _lib.load()
+    _chk(frames_u8, "frames", torch.uint8)
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
+    B, H, W, _ = frames_u8.shape
+    if out is None:
+        out = torch.empty(B, 3, H, W, device=frames_u8.device, dtype=torch.float32)
+    assert out.is_contiguous() and tuple(out.shape) == (B, 3, H, W) and out.dtype == torch.float32
+    _lib.check(L.pram_stage_frames_u8(_p(frames_u8), _p(lut), _p(out), B, H, W, _st()), "pram_stage_frames_u8")
+    return out
+
+
 def pack_record(kpts: torch.Tensor, scores: torch.Tensor, landmark: Optional[torch.Tensor] = None,
                 matches0: Optional[torch.Tensor] = None, mscores0: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> [B, k, 6] fp32: x, y, score, landmark id, match index, match score (pram_pack_record_f32); matches0 / mscores0 may cover

@@ -28,7 +28,10 @@ def test_bench_one_gpu_line(hip_lib):
               "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["dtype"].startswith("f32") and d["vs_baseline"] is None
-    assert d["parity"]["ok"] and d["parity"]["match"]["indices_identical"] and d["config"]["matches_last_step"] > 0
+    par = d["parity"]
+    assert par["ok"] and par["match_indices_identical"] and par["timed_record_identical"] and d["config"]["matches_last_step"] > 0
+    assert par["queries_checked"] == [0, 1] and len(par["per_query"]) == 2 and par["keypoint_set_identical"]      # the gate reads the timed batch itself
+    assert 0.9 <= par["keypoint_order_frac_min"] <= 1.0 and par["logits_maxdiff_max"] < 1e-3
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 0.05 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches_per_step"] == 33
@@ -44,7 +47,7 @@ def test_bench_latency_mode_line(hip_lib):
     c = d["config"]
     assert d["n_gpus"] == 1 and c["queries_per_step"] == 1 and c["batches_in_flight_per_gpu"] == 1 and c["hipgraph_replay"] is True
     assert c["attention_chunk_keys"] == 512 and "latency mode" in c["workload"]
-    assert d["parity"]["ok"] and d["parity"]["match"]["indices_identical"]
+    assert d["parity"]["ok"] and d["parity"]["match_indices_identical"] and d["parity"]["timed_record_identical"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.05 * d["value"] and d["ms_per_step"] < 20.0
     assert d["range_guard"]["x3_range_exceeded"] is False
 

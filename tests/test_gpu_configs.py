@@ -115,9 +115,9 @@ def test_c4_sfd2_extraction_k4096_vs_oracle(dev):
 
 
 def test_c5_fp16_path_nc513_4096(dev):
-    """C5: 'fp16 MFMA path', 4096 keypoints, 513 classes.  Own documented tolerance (single fp16 product per MAC), set at 2 x the
-    measurement (round 3: 3.3-4.05e-2 from the fp32 oracle, arg-max agreement 0.9961-0.9971 by the PRAM_F16_ACT setting): logits
-    within 8.1e-2, arg-max agreement >= 99.2 %; NOT the fp32 parity configuration."""
+    """C5: 'fp16 MFMA path', 4096 keypoints, 513 classes.  Own documented tolerance (single fp16 product per MAC), set at 1.5 x the
+    measurement (3.3-4.05e-2 from the fp32 oracle, arg-max agreement 0.9961-0.9971 by the PRAM_F16_ACT setting): logits
+    within 6.1e-2, arg-max agreement >= 99.42 % (= bench.F16_BARS, what alt.c5_f16.parity gates on); NOT the fp32 parity configuration."""
     desc, kp = _tokens(4096, idx=2)
     ref = R.segnetvit_forward(H.segnet_sd(513), desc, kp, (1, 3, 480, 640))
     net = _segnet(dev, 513).set_precision("f16")
@@ -127,7 +127,7 @@ def test_c5_fp16_path_nc513_4096(dev):
     net.set_precision(None)
     d3 = H.maxdiff(net({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(1, 3, 480, 640)})["prediction"], ref)
     print(f"C5 segnetvit N=4096 nc513: fp16 path |logit - oracle| {d:.2e}, argmax agreement {agree:.4f}; default path {d3:.2e}")
-    assert tuple(out.shape) == (1, 4096, 513) and d < 8.1e-2 and agree >= 0.992
+    assert tuple(out.shape) == (1, 4096, 513) and d < 6.1e-2 and agree >= 0.9942
     assert d3 < 1e-3
 
 

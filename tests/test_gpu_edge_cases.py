@@ -163,3 +163,25 @@ def test_models_on_tiny_inputs(dev):
     r = g.produce_matches({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}, p=0.0)
     o = R.gml_produce_matches(H.gml_sd(), data, p=0.0)
     assert torch.equal(r["matches0"].cpu(), o["matches0"]) and torch.equal(r["matches1"].cpu(), o["matches1"])
+
+
+def test_frame_staging_equals_the_reference_preparation(dev):
+    """pram_stage_frames_u8 = `torch.from_numpy(img / 255).permute(2, 0, 1).cuda().float()` + tvf.Normalize(mean, std)
+    (localization/loc_by_rec_online.py:98-106, nets/sfd2.py:14-17), bit for bit: every byte value in every channel, a 480 x 640
+    batch, and a frame whose pixel count is only a multiple of 4."""
+    from pram_amd import ops
+    from pram_amd.nets.sfd2 import RGB_mean, RGB_std
+    lut = ops.frame_lut(RGB_mean, RGB_std, dev)
+    g = torch.Generator().manual_seed(5)
+    for B, Hh, Ww in ((2, 480, 640), (1, 6, 10), (3, 16, 16)):
+        img = torch.randint(0, 256, (B, Hh, Ww, 3), generator=g, dtype=torch.uint8)
+        if (B, Hh, Ww) == (3, 16, 16):
+            img.view(-1)[:768] = torch.arange(256, dtype=torch.uint8).repeat(3)      # every byte value, in every channel phase
+        want = []
+        for b in range(B):
+            x = torch.from_numpy(img[b].numpy() / 255).permute(2, 0, 1).float()      # numpy float64 division, then .float()
+            m = torch.tensor(RGB_mean).view(3, 1, 1)
+            s = torch.tensor(RGB_std).view(3, 1, 1)
+            want.append(x.sub_(m).div_(s))                                          # tvf.Normalize
+        got = ops.stage_frames(img.to(dev), lut)
+        assert torch.equal(got.cpu(), torch.stack(want)), (B, Hh, Ww)
