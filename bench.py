@@ -781,13 +781,13 @@ def main():
         alt_run("exact_f32", "same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)", precision="f32")
         alt_run("gml_512x1024", "secondary matcher shape of SURVEY 8(d): the 512 best keypoints of a query against 1024-keypoint reference sets",
                 ref_kpts=1024, match_kpts=512)
+        alt_run("latency_b1", "one query per step, one step at a time, captured hipGraph replayed (the reference's online loop), 512-key attention chunks "
+                "(= python bench.py --latency); ms_per_step = per-query latency", steps_=30, warm_=10, B=1, inflight=1, use_graph=True, chunk=512)
         alt_run("c4", "BASELINE configs[3] shape (CambridgeLandmarks-like): 4096 keypoints, nc161, 8 queries per step, default (split-fp16) path",
                 kpts=4096, n_class=161, B=8)
         alt_run("c5_f16", "BASELINE configs[4] per-GPU shape (Aachen-like): 4096 keypoints, nc513, 8 queries per step, the 'fp16 MFMA path' "
                 "(--precision f16: one fp16 product per MAC — its own tolerance, see parity.bars)", kpts=4096, n_class=513, B=8, precision="f16",
                 parity_f16=True)
-        alt_run("latency_b1", "one query per step, one step at a time, captured hipGraph replayed (the reference's online loop), 512-key attention chunks "
-                "(= python bench.py --latency); ms_per_step = per-query latency", steps_=30, warm_=10, B=1, inflight=1, use_graph=True, chunk=512)
 
     if rank == 0:
         total_q = total_per_step * steps

@@ -14,7 +14,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (coordinate maps, rotary, Sinkhorn scaling); hot VALU loops call fmaf explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions to FLAGS (measured A/Bs: profiles/r05_*; MI355X_MICROARCH.md: packed fp32 VALU beside MFMAs is an anti-lever)
-FILE_FLAGS: dict[str, list[str]] = {}
+FILE_FLAGS: dict[str, list[str]] = {
+    # the soft-max of the attention kernel is scalar fp32 on purpose: SLP would re-pack it into v_pk_* (+18 clocks beside an MFMA)
+    "attention_x3.hip": ["-fno-slp-vectorize"],
+}
 
 
 def flags_for(src: Path) -> list[str]:

@@ -6,11 +6,13 @@
 //     x * 16 = hi + lo,  hi = fp16(16 x),  lo = fp16(16 x - hi)
 // and every product is three MFMAs accumulated in fp32 (gemm_core_x3.h has the error analysis):
 //     S^T = K_hi Q_hi + K_hi Q_lo + K_lo Q_hi            (= 256 K Q^T; the 1/256 rides in the softmax scale)
-//     O^T = V^T_hi P_hi + V^T_lo P_hi + V^T_hi P_lo       (P = 2^14 exp2(...) = P_hi + P_lo, = 2^18 V^T P)
-// The probabilities are scaled by 2^14 (an offset in the exponent argument: free) so that fp16 keeps 11 bits for every
-// probability above 2^-28 of the row maximum.  PSPLIT = false (pram_attention_x3_set_p_split(0), from 1024 keys on) drops the
-// P_lo product: P is then ONE fp16 whose rounding (2^-12 relative per probability) does not average out of flat attention —
-// the output is a small difference of large terms — and shows as 7e-4 on SegNetViT's logits against 4e-5; the row sum then
+//     O^T = V^T_lo P_hi + V^T_hi P_hi + V^T_hi P_lo       (P = 2^7 exp2(s - m) = P_hi + P_lo, = 2^11 V^T P)
+// The probabilities are scaled by 2^7 (an offset in the exponent argument: free) and the running maximum m is LAZY: it follows the
+// row maximum only when it is left behind by more than 2^8 (LAZY_T), so P <= 2^15 fits fp16, the two parts keep an absolute
+// 2^-25 (fp16 subnormals are kept by the MFMA), and the rescale of the output accumulators — exactly 1 on almost every tile — is
+// skipped by a wave-uniform branch.  PSPLIT = false (pram_attention_x3_set_p_split(0), from 1024 keys on) drops the P_lo
+// product: P is then ONE fp16 whose rounding (2^-12 relative per probability) does not average out of flat attention — the
+// output is a small difference of large terms — and shows as ~1e-3 on SegNetViT's logits against 4e-5; the row sum then
 // accumulates the same rounded values, so scale and rounding bias cancel in the normalisation.
 //
 // Register design as attention.hip / attention_f16.hip: everything transposed so that the query row is the lane
@@ -28,56 +30,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int D = 64, QW = 32, NW = 4, BQ = QW * NW, BKV = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3::ACT_SCALE)
-// Build knobs of the pipelined kernel's soft-max (profiles/r05_x3_attention_valu_diet.txt has the A/B of each):
-#ifndef AX_SCALAR
-#define AX_SCALAR 0      // 1: scalar fp32 VALU (v_fma_f32 / v_mul_f32) instead of packed (v_pk_*): compile with -fno-slp-vectorize as well
-#endif
-#ifndef AX_MIX
-#define AX_MIX 0         // 1: the probabilities' lo parts by v_fma_mixlo / mixhi_f16
-#endif
-#ifndef AX_SWAP
-#define AX_SWAP 0        // 1: the half-waves exchange their row maxima by v_permlane32_swap instead of ds_bpermute
-#endif
-#ifndef AX_LAZY
-#define AX_LAZY 0        // 1: lazy running maximum (threshold LAZY_T), output accumulators rescaled only when a lane's maximum moved
-#endif
-#ifndef AX_SPREAD
-#define AX_SPREAD 0      // 1: the soft-max arithmetic spread over BOTH matrix phases of a tile (implies SCALAR, MIX, SWAP, LAZY) — see softmax_a / pv_b
-#endif
-#if AX_SPREAD
-#undef AX_SCALAR
-#undef AX_MIX
-#undef AX_SWAP
-#undef AX_LAZY
-#define AX_SCALAR 1
-#define AX_MIX 1
-#define AX_SWAP 1
-#define AX_LAZY 1
-#endif
-#ifndef AX_VPA
-#define AX_VPA 4         // AX_SPREAD: vector instructions behind each score MFMA (phase A) ...
-#endif
-#ifndef AX_VPB
-#define AX_VPB 4         // ... and behind each P V MFMA (phase B)
-#endif
-#ifndef AX_MAXG
-#define AX_MAXG 7        // AX_SPREAD: leading MFMA groups of phase A that carry the row maximum (4 vector instructions each)
-#endif
-#ifndef AX_PRIO
-#define AX_PRIO 0        // 1: static s_setprio 1 for waves 4-7 of the eight-wave workgroup
-#endif
-#ifndef AX_VPM
-#define AX_VPM 6         // vector instructions scheduled behind each score MFMA of the interleaved region
-#endif
-#ifndef AX_VPM_HI
-#define AX_VPM_HI 18
-#endif
-#if AX_LAZY
-constexpr float LAZY_T = 8.0f;
+constexpr float LAZY_T = 8.0f;          // lazy running maximum: it follows the row maximum only when left behind by more than 2^8
+constexpr int MAXG = 7;                 // leading MFMA groups of a tile's score phase that carry the row maximum (4 vector instructions each)
 constexpr float P_EXP_SHIFT = 7.0f;     // probabilities carried as 2^7 p, at most 2^15 with the lazy maximum LAZY_T behind
-#else
-constexpr float P_EXP_SHIFT = 14.0f;    // probabilities carried as 2^14 p
-#endif
 
 struct ArgsX {
     const _Float16* qh; const _Float16* ql; const _Float16* kh; const _Float16* kl;
@@ -147,244 +102,20 @@ __device__ __forceinline__ int pos_of_key(int key) {
     return t * 32 + u * 16 + h * 8 + i;
 }
 
-// ABL: profiling ablations (PRAM_ATTN_ABLATE, never set in production): bit 0 skips the softmax arithmetic, bit 1 the LDS
-// fragment reads after the first, bit 2 the K / V staging — results are garbage, the remaining work keeps its shape.
-// PSPLIT: the probabilities enter P V split like every other operand (three MFMAs per product, 22-bit P) instead of as one fp16
-// (two MFMAs): used below 1024 keys, where the per-key rounding of single-fp16 probabilities does not average out.
-template <int ABL, bool PSPLIT>
-__global__ __launch_bounds__(256, 2) void attention_x3_kernel(ArgsX p) {
-    __shared__ Smem s;
-    const int nblk = p.batch * p.heads * p.q_tiles;
-    const int id = xcd_remap(blockIdx.x, nblk);
-    const int qt = id % p.q_tiles;
-    const int bh = id / p.q_tiles;
-    const int head = bh % p.heads, b = bh / p.heads;
-    const int qlen = p.q_lens ? p.q_lens[b] : p.m_max;
-    const int kb = p.kv_shift ? (b + p.kv_shift) % p.batch : b;
-    const int klen = p.k_lens ? p.k_lens[kb] : p.n_max;
-    if (qt * BQ >= qlen) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int q0 = qt * BQ + wave * QW;
-    const bool wave_active = q0 < qlen;
-    const int qrow = q0 + r;
-    const bool q_ok = qrow < qlen;
-    if (klen <= 0) {   // empty key set: context defined as 0 (see attention.hip)
-        if (q_ok) {
-            float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(op + c * 8 + h * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = 0.f;
-        }
-        return;
-    }
-
-    const size_t qoff = ((size_t)b * p.m_max + min(qrow, p.m_max - 1)) * p.ldq + head * D;
-    const size_t koff = (size_t)kb * p.n_max * p.ldk + head * D;
-    const size_t voff = ((size_t)kb * p.heads + head) * D * p.tv;
-
-    // Q fragments: q?[c][i] = plane(Q[qrow][16c + 8h + i])
-    half8 qh[4], ql[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        qh[c] = *reinterpret_cast<const half8*>(p.qh + qoff + c * 16 + h * 8);
-        ql[c] = *reinterpret_cast<const half8*>(p.ql + qoff + c * 16 + h * 8);
-        if (!q_ok)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { qh[c][i] = (_Float16)0.f; ql[c][i] = (_Float16)0.f; }
-    }
-
-    // staging: K rows are keys (halves 8*lseg .. +7 of key lrow + 32p); V^T rows are head dims (positions 8*lseg .. +7 of
-    // dim lrow + 32p): both are plain 16-byte copies.  Keys beyond klen: the K row is a duplicate of the last valid key
-    // (its scores are masked to -inf), the V^T positions hold zeros (vt_kernel), so P = 0 meets a finite value.
-    const int lrow = tid >> 3, lseg = tid & 7;
-    half8 krh[2], krl[2], vrh[2], vrl[2];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const size_t kc = (size_t)min(kt * BKV + lrow + 32 * pp, klen - 1);
-            krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
-            krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
-            const size_t vo = voff + (size_t)(lrow + 32 * pp) * p.tv + kt * BKV + lseg * 8;
-            vrh[pp] = *reinterpret_cast<const half8*>(p.vh + vo);
-            vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int row = lrow + 32 * pp;
-            const int off = row * D + ((lseg ^ ((row >> 1) & 7)) << 3);      // K [key][d] and V^T [d][pos]: same 128-B rows, same swizzle
-            *reinterpret_cast<half8*>(&s.kh[buf][off]) = krh[pp];
-            *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
-            *reinterpret_cast<half8*>(&s.vth[buf][off]) = vrh[pp];
-            *reinterpret_cast<half8*>(&s.vtl[buf][off]) = vrl[pp];
-        }
-    };
-
-    const int nkt = (klen + BKV - 1) / BKV;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    float m_run = -1.0e30f, l_run = 0.f;
-    f32x16 oacc[2];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more && !(ABL & 4)) gload(kt + 1);
-
-        if (wave_active) {
-            f32x16 st[2];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
-            // K fragments of step c + 1 are requested before the MFMAs of step c (pinned with sched_barrier: hipcc otherwise
-            // sinks each ds_read next to its first use and every MFMA group starts with an exposed LDS round trip)
-            struct KFrag { half8 h0, h1, l0, l1; };
-            auto kload = [&](int c, KFrag& f) {
-                const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;   // ((32 + r) >> 1) & 7 == (r >> 1) & 7
-                f.h0 = *reinterpret_cast<const half8*>(&s.kh[cur][r * D + slot]);
-                f.h1 = *reinterpret_cast<const half8*>(&s.kh[cur][(32 + r) * D + slot]);
-                f.l0 = *reinterpret_cast<const half8*>(&s.kl[cur][r * D + slot]);
-                f.l1 = *reinterpret_cast<const half8*>(&s.kl[cur][(32 + r) * D + slot]);
-            };
-            auto kmma = [&](int c, const KFrag& f) {
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, qh[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, qh[c], st[1], 0, 0, 0);
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ql[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ql[c], st[1], 0, 0, 0);
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, qh[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, qh[c], st[1], 0, 0, 0);
-            };
-            KFrag ka, kb2;
-            kload(0, ka);
-            kload(1, kb2);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma(0, ka);
-            if (!(ABL & 2)) kload(2, ka);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma(1, kb2);
-            if (!(ABL & 2)) kload(3, kb2);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma(2, ka);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma(3, kb2);
-            // the V^T fragments of the first two PV steps travel under the softmax arithmetic
-            struct VFrag { half8 h0, h1, l0, l1; };
-            auto vload = [&](int t, int u, VFrag& f) {
-                const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
-                f.h0 = *reinterpret_cast<const half8*>(&s.vth[cur][r * BKV + slot]);
-                f.h1 = *reinterpret_cast<const half8*>(&s.vth[cur][(32 + r) * BKV + slot]);
-                f.l0 = *reinterpret_cast<const half8*>(&s.vtl[cur][r * BKV + slot]);
-                f.l1 = *reinterpret_cast<const half8*>(&s.vtl[cur][(32 + r) * BKV + slot]);
-            };
-            VFrag va, vb;
-            vload(0, 0, va);
-            vload(0, 1, vb);
-            if (!more && (klen & (BKV - 1))) {
-                const int kbase = kt * BKV;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (kbase + t * 32 + key_of(e, h) >= klen) st[t][e] = -INFINITY;
-            }
-            float tmax = st[0][0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax * p.scale2);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            const float shift = P_EXP_SHIFT - m_new;
-            // The probabilities enter P V as ONE fp16 (P_hi): two MFMAs per product (V_lo P_hi + V_hi P_hi) instead of three, and
-            // no splitting arithmetic — this kernel is bound by its softmax VALU, not by the matrix pipe.  The row sum is taken
-            // over the SAME rounded values (v_dot2_f32_f16 against (1, 1): exact fp32 accumulation of the fp16 pairs), so the
-            // 2^-12 relative rounding of each probability perturbs only the softmax WEIGHTS' ratios, independently per key:
-            // measured end to end against the fp32 oracle 4.6e-5 on the SegNetViT logits (1.4e-5 with P split as well), matcher
-            // indices identical (profiles/tools/split_emulation.py --p-hi-only).
-            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-            const half2_t ones = {(_Float16)1.f, (_Float16)1.f};
-            float psum = 0.f;
-            half8 ph[2][2], pl[2][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const float p0 = (ABL & 1) ? st[t][e] : __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale2, shift));       // v_exp_f32: argument <= 14
-                    const float p1 = (ABL & 1) ? st[t][e + 1] : __builtin_amdgcn_exp2f(fmaf(st[t][e + 1], p.scale2, shift));
-                    const half2_t pk = {(_Float16)p0, (_Float16)p1};
-                    ph[t][e >> 3][e & 7] = pk[0];
-                    ph[t][e >> 3][(e & 7) + 1] = pk[1];
-                    if constexpr (PSPLIT) {
-                        psum += p0 + p1;
-                        pl[t][e >> 3][e & 7] = (_Float16)(p0 - (float)pk[0]);
-                        pl[t][e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)pk[1]);
-                    } else {
-                        psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
-                    }
-                }
-            l_run = fmaf(l_run, alpha, psum);
-            m_run = m_new;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
-            auto vmma = [&](int t, int u, const VFrag& f) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, ph[t][u], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, ph[t][u], oacc[1], 0, 0, 0);
-                if constexpr (PSPLIT) {
-                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pl[t][u], oacc[0], 0, 0, 0);
-                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pl[t][u], oacc[1], 0, 0, 0);
-                }
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, ph[t][u], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, ph[t][u], oacc[1], 0, 0, 0);
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            vmma(0, 0, va);
-            if (!(ABL & 2)) vload(1, 0, va);
-            __builtin_amdgcn_sched_barrier(0);
-            vmma(0, 1, vb);
-            if (!(ABL & 2)) vload(1, 1, vb);
-            __builtin_amdgcn_sched_barrier(0);
-            vmma(1, 0, va);
-            __builtin_amdgcn_sched_barrier(0);
-            vmma(1, 1, vb);
-        }
-        if (more && !(ABL & 4)) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    if (!wave_active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (1.0f / IN_SCALE) / l_tot;       // undoes the 2^14 of P (carried by l_tot) and the 16 of V
-    if (q_ok) {
-        float* op = p.out + ((size_t)b * p.m_max + qrow) * p.ldo + head * D;
-#pragma unroll
-        for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 o = make_float4(oacc[dn][4 * g + 0] * inv, oacc[dn][4 * g + 1] * inv,
-                                             oacc[dn][4 * g + 2] * inv, oacc[dn][4 * g + 3] * inv);
-                *reinterpret_cast<float4*>(op + dn * 32 + 8 * g + 4 * h) = o;
-            }
-        if (p.lse2 && h == 0) p.lse2[((size_t)b * p.heads + head) * p.m_max + qrow] = m_run + (log2f(l_tot) - P_EXP_SHIFT);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// Software-pipelined variant (the default).  The kernel above is bound by its soft-max arithmetic: per 64-key tile a wave
-// issues 40 MFMAs (1 280 matrix cycles) and ~1 000 cycles of VALU work (32 v_exp_f32 at quarter rate, max, scale, convert, sum,
-// rescale), strictly one after the other — S must be complete before the soft-max, P before P V — so within a wave the matrix
-// pipe idles through the whole soft-max, and only the second wave of the SIMD can fill the gap (PMC: MfmaUtil 45 %).
-// Here the scores of tile j + 1 are multiplied WHILE the soft-max of tile j runs: the 24 MFMAs of S_{j+1} and the VALU
-// instructions of softmax(S_j) sit in one scheduling region and are interleaved one MFMA : six VALU (sched_group_barrier), so a
-// wave keeps both pipes busy on its own.  Costs: a second 32-register score tile, and K staged one tile ahead of V (K_{j+2} and
-// V_{j+1} land while K_{j+1} and V_j are read: same 64 KB of LDS).  The arithmetic — and every bit of the result — is that of
-// the kernel above; the soft-max is written with packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32).
+// The kernel.  Per 64-key tile a wave issues 48 MFMAs (1 608 clocks of its SIMD's matrix pipe) and ~190 vector instructions
+// (~1 000 clocks of vector issue: a VOP2 costs a wave 4 clocks, a VOP3 5, v_exp_f32 and v_fma_mix 8; beside one MFMA = 33.5 clocks a
+// wave hides ~23 of them — profiles/r05_mfma_valu_overlap.txt).  Both pipes are nearly full, so the tile loop is built around
+// WHERE the vector work sits (round 5; profiles/r05_x3_attention_valu_diet.txt has every step's A/B):
+//   * software pipeline across tiles: the scores of tile j + 1 are multiplied while the soft-max of tile j runs (a second
+//     32-register score tile; K staged one tile ahead of V: K_{j+2} and V_{j+1} land while K_{j+1} and V_j are read);
+//   * the soft-max is split over BOTH matrix phases of a tile (softmax_a beside S_{j+1} = K_{j+1} Q^T, the fp16 parts and the row
+//     sums inside pv_b beside O += V_j P_j), one MFMA : 3-4 vector instructions by sched_group_barrier — bunched behind the score
+//     MFMAs alone it made that phase issue-bound (42 clocks per MFMA) and left the P V MFMAs bare: the younger wave of every SIMD
+//     needed 3 760 clocks for the phase while the older one waited 1 900 at the barrier (profiles/r05_attn_phases.txt);
+//   * no packed fp32 (v_pk_*: +18 clocks beside an MFMA, measured) — the file is built with -fno-slp-vectorize; the lo parts by
+//     v_fma_mixlo / mixhi_f16 (one instruction per element instead of convert, subtract, convert); the half-waves trade row maxima
+//     by v_permlane32_swap instead of ds_bpermute; the lazy maximum above.
 // HI: single-product mode (BASELINE C5's fp16 path): only the hi planes exist (q / k / v rounded to fp16, scale p.in_scale = 1),
 // one MFMA per product; half the LDS, so the co-residency is bounded by registers only.
 // MODE 0: one online soft-max over all keys (one key chunk: every launch at the default chunk size); 1: fused, key chunks folded
@@ -536,12 +267,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     f32x16 oacc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
-#if AX_MIX
-    typedef int int4v __attribute__((ext_vector_type(4)));
-    int4v ph[2][2], pl[2][2];          // packed fp16 pairs: register j of ph[t][u] holds the probabilities of score registers 8u + 2j, 8u + 2j + 1
-#else
-    half8 ph[2][2], pl[2][2];
-#endif
     // Chunk bookkeeping.  MODE 1 (fused): a running total (o_tot, l_tot2) is folded at every chunk end by the left fold
     // combine_x3_kernel applies; it does not fit beside the two score tiles of the software pipeline (256 registers at two waves
     // per SIMD), the compiler spills and reloads it around the chunk end: +6 % for two 2048-key chunks, +17 % at 512.  MODE 2 (split):
@@ -622,154 +347,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             l_tot2 = lse_c;
         }
     };
-    // O *= alpha.  AX_LAZY: called between the interleaved score / soft-max region and P V, skipped when no lane's maximum moved
+    // O *= alpha, between the two matrix phases of a tile; skipped when no lane's running maximum moved (alpha is exactly 1 on
+    // almost every tile: the maximum is lazy, see softmax_a)
     auto rescale = [&](float alpha) {
-#if AX_LAZY
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) return;
-#endif
-#if AX_SCALAR
 #pragma unroll
         for (int dn = 0; dn < 2; ++dn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[dn][e] *= alpha;
-#else
-        const f2 al2 = {alpha, alpha};
-#pragma unroll
-        for (int dn = 0; dn < 2; ++dn)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const f2 o = (f2){oacc[dn][e], oacc[dn][e + 1]} * al2;
-                oacc[dn][e] = o[0];
-                oacc[dn][e + 1] = o[1];
-            }
-#endif
     };
-    // softmax(S) of one tile: running max / sum, the probabilities as fp16 (and their residuals when PSPLIT), O rescaled.
-    // Returns alpha, the factor the caller owes the output accumulators (AX_LAZY: applied by rescale() outside the interleaved region).
-    auto softmax = [&](f32x16 (&st)[2]) -> float {
-        float tmax = st[0][0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[1][e]);
-#if AX_SWAP
-        {   // the other half-wave's maximum by v_permlane32_swap (a vector-ALU move) instead of ds_bpermute (an LDS round trip)
-            float a = tmax, b = tmax;
-            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-            tmax = fmaxf(a, b);
-        }
-#else
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-#endif
-#if AX_LAZY
-        // the running maximum follows the row maximum only when it is left behind by more than LAZY_T (log2 units): the
-        // probabilities then reach 2^(P_EXP_SHIFT + LAZY_T) at most, alpha is exactly 1 on almost every tile
-        const float t2 = tmax * p.scale2;
-        const float m_new = (t2 > m_run + LAZY_T) ? t2 : m_run;
-#else
-        const float m_new = fmaxf(m_run, tmax * p.scale2);
-#endif
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        const float shift = P_EXP_SHIFT - m_new;
-        const half2_t ones = {(_Float16)1.f, (_Float16)1.f};
-        float psum = 0.f;
-#if AX_LAZY
-        float ps4[4] = {0.f, 0.f, 0.f, 0.f};      // four partial row sums: no 16-deep dependent chain in front of P V
-#endif
-#if AX_SCALAR
-        const float sc = p.scale2;
-#else
-        const f2 sc2 = {p.scale2, p.scale2}, sh2 = {shift, shift};
-#endif
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-#if AX_SCALAR
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(st[t][e], sc, shift));       // argument <= P_EXP_SHIFT (+ LAZY_T)
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(st[t][e + 1], sc, shift));
-#else
-                const f2 y = __builtin_elementwise_fma((f2){st[t][e], st[t][e + 1]}, sc2, sh2);      // one rounding, like fmaf
-                const float p0 = __builtin_amdgcn_exp2f(y[0]);       // argument <= 14
-                const float p1 = __builtin_amdgcn_exp2f(y[1]);
-#endif
-#if AX_MIX
-                const half2_t pk = __builtin_convertvector((f2){p0, p1}, half2_t);      // v_cvt_pk_f16_f32
-                const int hi2 = __builtin_bit_cast(int, pk);
-                ph[t][e >> 3][(e & 7) >> 1] = hi2;
-                if constexpr (PSPLIT) {
-#if AX_LAZY
-                    ps4[(e >> 1) & 3] += p0 + p1;
-#else
-                    psum += p0 + p1;
-#endif
-                    // lo = fp16(p - hi) in ONE instruction per element (v_fma_mixlo / mixhi_f16: p * 1 - hi with hi read as fp16 from its
-                    // half of the packed register) instead of convert back, subtract, convert: the same value, bit for bit
-                    int lo2;
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(lo2) : "v"(p0), "v"(p1), "v"(hi2));
-                    pl[t][e >> 3][(e & 7) >> 1] = lo2;
-                } else {
-                    psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
-                }
-#else
-                const half2_t pk = {(_Float16)p0, (_Float16)p1};
-                ph[t][e >> 3][e & 7] = pk[0];
-                ph[t][e >> 3][(e & 7) + 1] = pk[1];
-                if constexpr (PSPLIT) {
-                    psum += p0 + p1;
-                    pl[t][e >> 3][e & 7] = (_Float16)(p0 - (float)pk[0]);
-                    pl[t][e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)pk[1]);
-                } else {
-                    psum = __builtin_amdgcn_fdot2(pk, ones, psum, false);
-                }
-#endif
-            }
-#if AX_LAZY
-        if constexpr (PSPLIT) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-#endif
-        l_run = fmaf(l_run, alpha, psum);
-        m_run = m_new;
-#if !AX_LAZY
-        rescale(alpha);
-#endif
-        return alpha;
-    };
-#if AX_MIX
-#define PB(x) __builtin_bit_cast(half8, x)
-#else
-#define PB(x) (x)
-#endif
-    auto vmma = [&](int t, int u, const VFrag& f) {
-        if constexpr (!HI) {
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, PB(ph[t][u]), oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, PB(ph[t][u]), oacc[1], 0, 0, 0);
-        }
-        if constexpr (PSPLIT) {
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(pl[t][u]), oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(pl[t][u]), oacc[1], 0, 0, 0);
-        }
-        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(ph[t][u]), oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(ph[t][u]), oacc[1], 0, 0, 0);
-    };
-    auto pv = [&](int vbuf) {
-        VFrag va, vb;
-        vload(vbuf, 0, 0, va);
-        vload(vbuf, 0, 1, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        vmma(0, 0, va);
-        vload(vbuf, 1, 0, va);
-        __builtin_amdgcn_sched_barrier(0);
-        vmma(0, 1, vb);
-        vload(vbuf, 1, 1, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        vmma(1, 0, va);
-        __builtin_amdgcn_sched_barrier(0);
-        vmma(1, 1, vb);
-    };
-
-
-#if AX_SPREAD
     // The vector ALU is the second bound of this kernel (profiles/r05_mfma_valu_overlap.txt: beside one v_mfma_f32_32x32x16_f16 =
     // 33.5 clocks a wave hides ~23 clocks of vector issue — a VOP2 costs 4, a VOP3 5, v_exp_f32 and v_fma_mix 8 — and the two waves
     // of a SIMD share the issue port).  One tile's soft-max is ~1 000 such clocks; bunched behind the 24 score MFMAs (42 per MFMA)
@@ -802,15 +388,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         return alpha;
     };
     // the fp16 hi parts of one 16-key quarter (four v_cvt_pk_f16_f32; the single-product mode sums the rounded values here)
-    auto hi_parts = [&](int t, int u, f32x16 (&st)[2], float& psum) -> int4v {
-        int4v hi;
+    // (kept as four separate packed pairs: taking the fp16 halves back out of an int4 / half8 vector for v_fma_mix made this
+    // compiler read every pair's hi part from element 0 — profiles/r05_x3_attention_valu_diet.txt)
+    struct Hi4 { half2_t v[4]; };
+    auto hi_parts = [&](int t, int u, f32x16 (&st)[2], float& psum) -> Hi4 {
+        Hi4 hi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const half2_t pk = __builtin_convertvector((f2){st[t][8 * u + 2 * j], st[t][8 * u + 2 * j + 1]}, half2_t);
-            hi[j] = __builtin_bit_cast(int, pk);
-            if constexpr (!PSPLIT) psum = __builtin_amdgcn_fdot2(pk, (half2_t){(_Float16)1.f, (_Float16)1.f}, psum, false);
+            hi.v[j] = __builtin_convertvector((f2){st[t][8 * u + 2 * j], st[t][8 * u + 2 * j + 1]}, half2_t);      // v_cvt_pk_f16_f32
+            if constexpr (!PSPLIT) psum = __builtin_amdgcn_fdot2(hi.v[j], (half2_t){(_Float16)1.f, (_Float16)1.f}, psum, false);
         }
         return hi;
+    };
+    auto pack4 = [&](const Hi4& x) -> half8 {
+        return (half8){x.v[0][0], x.v[0][1], x.v[1][0], x.v[1][1], x.v[2][0], x.v[2][1], x.v[3][0], x.v[3][1]};
     };
     // part B + P V of one tile, written in the order it is meant to issue (the sched_group_barriers behind the call pin it): per
     // 16-key quarter the four products that take P_hi, each followed by one element pair's lo parts (v_fma_mixlo / mixhi) and its
@@ -818,12 +409,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     // va / vb: the V^T fragments of the first two quarters, already requested.
     auto pv_b = [&](int vbuf, f32x16 (&st)[2], float alpha, VFrag& va, VFrag& vb) {
         float ps4[4] = {0.f, 0.f, 0.f, 0.f}, psum = 0.f;
-        int4v hi = hi_parts(0, 0, st, psum);
+        Hi4 hi = hi_parts(0, 0, st, psum);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int t = qd >> 1, u = qd & 1;
             VFrag& f = u ? vb : va;
-            int4v lo;
+            Hi4 lo;
             float pair[4];
             auto lo_pair = [&](int j) {
                 if constexpr (PSPLIT) {
@@ -831,29 +422,28 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                     // lo = fp16(p - hi) as ONE instruction per element: fma(p, 1, -hi) with the 1 hidden from the optimiser selects
                     // v_fma_mixlo / mixhi_f16 (hi read as fp16 from its half of the packed register); a plain p - (float)hi would be
                     // convert, subtract, convert.  Same value bit for bit (the difference is exact in fp32).
-                    const half2_t hk = __builtin_bit_cast(half2_t, hi[j]);
-                    const half2_t lk = {(_Float16)__builtin_fmaf(p0, one, -(float)hk[0]), (_Float16)__builtin_fmaf(p1, one, -(float)hk[1])};
-                    lo[j] = __builtin_bit_cast(int, lk);
+                    const half2_t hk = hi.v[j];
+                    lo.v[j] = (half2_t){(_Float16)__builtin_fmaf(p0, one, -(float)hk[0]), (_Float16)__builtin_fmaf(p1, one, -(float)hk[1])};
                     pair[j] = p0 + p1;
                 }
             };
             if constexpr (!HI) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, PB(hi), oacc[0], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, pack4(hi), oacc[0], 0, 0, 0);
                 lo_pair(0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, PB(hi), oacc[1], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, pack4(hi), oacc[1], 0, 0, 0);
                 lo_pair(1);
             }
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(hi), oacc[0], 0, 0, 0);
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(hi), oacc[0], 0, 0, 0);
             lo_pair(2);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(hi), oacc[1], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(hi), oacc[1], 0, 0, 0);
             lo_pair(3);
-            int4v nhi = hi;
+            Hi4 nhi = hi;
             if (qd < 3) nhi = hi_parts((qd + 1) >> 1, (qd + 1) & 1, st, psum);
             if constexpr (PSPLIT) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, PB(lo), oacc[0], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(lo), oacc[0], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ps4[j] += pair[j];
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, PB(lo), oacc[1], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(lo), oacc[1], 0, 0, 0);
             }
             hi = nhi;
             if (qd == 0) vload(vbuf, 1, 0, va);       // this quarter is through with va / vb: the fragments of quarter qd + 2
@@ -862,7 +452,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         if constexpr (PSPLIT) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         l_run = fmaf(l_run, alpha, psum);
     };
-#endif
 
     // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own  (tile numbers relative to t0, which is even: the
     // stage parity of a tile is that of its absolute number)
@@ -909,7 +498,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         PROF_STAMP(0);
         gload_v(j + 1);
         if (more_k) gload_k(j + 2);
-#if AX_SPREAD
         if (wave_active) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
@@ -937,7 +525,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             for (int g = 0; g < (HI ? 8 : 24); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (g < (HI ? 8 : 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (g < (HI ? 2 : AX_MAXG)) __builtin_amdgcn_sched_group_barrier(0x002, HI ? 16 : 4, 0);
+                if (g < (HI ? 2 : MAXG)) __builtin_amdgcn_sched_group_barrier(0x002, HI ? 16 : 4, 0);
                 else {
                     __builtin_amdgcn_sched_group_barrier(0x002, HI ? 6 : 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x400, HI ? 6 : 2, 0);
@@ -976,40 +564,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             __builtin_amdgcn_sched_barrier(0);
             PROF_STAMP(2);
         }
-#else
-        if (wave_active) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
-            KFrag fa, fb;
-            kload(kbuf, 0, fa);
-            kload(kbuf, 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma(sn, 0, fa);
-            kload(kbuf, 2, fa);
-            kmma(sn, 1, fb);
-            kload(kbuf, 3, fb);
-            kmma(sn, 2, fa);
-            kmma(sn, 3, fb);
-            const float alpha = softmax(sc);
-            // one MFMA, then VALU work of the soft-max in its shadow; the eight fragment reads go out with the first groups
-#pragma unroll
-            for (int g = 0; g < (HI ? 8 : 24); ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g < (HI ? 4 : 8)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, HI ? AX_VPM_HI : AX_VPM, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            PROF_STAMP(1);
-#if AX_LAZY
-            rescale(alpha);
-            __builtin_amdgcn_sched_barrier(0);
-#else
-            (void)alpha;
-#endif
-            pv(vbuf);
-            PROF_STAMP(2);
-        }
-#endif
         lstore_v((j + 1) & 1);
         if (more_k) lstore_k(j & 1);
         PROF_STAMP(3);
@@ -1020,9 +574,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         prof_ph[2] += prof_ts[3] - prof_ts[2]; prof_ph[3] += prof_ts[4] - prof_ts[3];
 #endif
     };
-#if AX_PRIO
-    if (NWV == 2 * NW && wave >= NW) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every VALU arbitration otherwise
-#endif
     int j = t0;
     if constexpr (MODE != 0) {
         // Whole key chunks that are followed by at least one more tile: eight tiles (the score-tile ping-pong comes back to
@@ -1056,7 +607,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
                 for (int e = 0; e < 16; ++e)
                     if (kbase + t * 32 + key_of(e, h) >= klen) sc[t][e] = -INFINITY;
         }
-#if AX_SPREAD
         VFrag va, vb;
         vload((nkt - 1) & 1, 0, 0, va);
         vload((nkt - 1) & 1, 0, 1, vb);
@@ -1064,16 +614,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         rescale(alpha);
         __builtin_amdgcn_sched_barrier(0);
         pv_b((nkt - 1) & 1, sc, alpha, va, vb);
-#else
-        const float alpha = softmax(sc);
-#if AX_LAZY
-        rescale(alpha);
-#else
-        (void)alpha;
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        pv((nkt - 1) & 1);
-#endif
     };
     if (in_a) last(sa); else last(sb);
     finish();
@@ -1454,16 +994,9 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
             scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift, IN_SCALE, 1, 0, chunk_tiles(), nullptr, nullptr};
-#ifdef PRAM_PROFILING      // the non-pipelined kernel and its ablations (garbage results, PRAM_OK): profiling builds only
-    static const char* abl = getenv("PRAM_ATTN_ABLATE");
-    static const char* v1 = getenv("PRAM_ATTN_V1");
-#else
-    constexpr const char* abl = nullptr;
-    constexpr const char* v1 = nullptr;
-#endif
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (!(v1 && v1[0] == '1') && !abl) {
+    {
         if (n_max < 1024) {
             hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0>), grid, blk, 0, st, p);
             return pram_launch_status("pram_attention_x3_f32");
@@ -1509,22 +1042,6 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
         hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
     }
-#ifdef PRAM_PROFILING
-    // PRAM_ATTN_V1 / PRAM_ATTN_ABLATE (profiling): the non-pipelined kernel — one online soft-max over all keys, so its results
-    // differ from the chunked default in the last bits
-    if (n_max < 1024) {
-        hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p);
-        return pram_launch_status("pram_attention_x3_f32");
-    }
-    switch (abl ? atoi(abl) : 0) {
-        case 1: hipLaunchKernelGGL((attention_x3_kernel<1, false>), grid, blk, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((attention_x3_kernel<2, false>), grid, blk, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((attention_x3_kernel<4, false>), grid, blk, 0, st, p); break;
-        case 7: hipLaunchKernelGGL((attention_x3_kernel<7, false>), grid, blk, 0, st, p); break;
-        case 8: hipLaunchKernelGGL((attention_x3_kernel<0, true>), grid, blk, 0, st, p); break;
-        default: hipLaunchKernelGGL((attention_x3_kernel<0, false>), grid, blk, 0, st, p);
-    }
-#endif
     return pram_launch_status("pram_attention_x3_f32");
 }
 
