@@ -450,7 +450,7 @@ class Job:
     hipGraph per lane) and the step function."""
 
     def __init__(self, dev, rank, world, q0, B, matcher_name, kpts, n_class, stages, inflight, use_graph, precision=None,
-                 ref_kpts=0, match_kpts=0, shard_sizes=None):
+                 ref_kpts=0, match_kpts=0, shard_sizes=None, segk=0, h2d=False):
         from pram_amd import ops, weights as Wt
         from pram_amd.pipeline import GraphedPipeline, QueryPipeline
         self.dev, self.world, self.B, self.stages, self.matcher_name = dev, world, B, stages, matcher_name
@@ -482,13 +482,88 @@ class Job:
                 self.ref, self.gt = make_reference_sets(ex["descriptors"], ex["keypoints"], ex["scores"], self.counts, 5000 + q0,
                                                         n_ref=ref_kpts, m_match=match_kpts)
             del ex
+        self.segk, self.h2d = int(segk), bool(h2d)
+        if self.segk:
+            self._build_segk(q0, kpts)
+            use_graph = False
+        if self.h2d:
+            # the reference's per-frame preparation inside the step (localization/loc_by_rec_online.py:86-106): uint8 frames in
+            # pinned host memory -> one H2D copy per step on the lane's stream -> pram_stage_frames_u8 (/ 255, Normalize, HWC -> CHW)
+            from pram_amd.nets.sfd2 import RGB_mean, RGB_std
+            m = torch.tensor(RGB_mean).view(1, 3, 1, 1)
+            sd_ = torch.tensor(RGB_std).view(1, 3, 1, 1)
+            u8 = ((self.images.cpu() * sd_ + m) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            self.host_u8 = u8.pin_memory()
+            self.dev_u8 = torch.empty_like(u8, device=dev)
+            self.lut = ops.frame_lut(RGB_mean, RGB_std, dev)
+            self.images = ops.stage_frames(u8.to(dev), self.lut)      # what the staged frames are (the resident run rounds differently)
+            use_graph = False
         self.lanes = [torch.cuda.Stream(device=dev) for _ in range(inflight)] if inflight > 1 else None
         self.graphs = None
         if use_graph:
             # one captured step per lane: the host's share of a step drops from ~3 ms of ctypes launches to one graph launch
             # (what matters with eight ranks on a cgroup-limited host); GPU work is the same kernels in the same order
-            self.graphs = [GraphedPipeline(self.pipe, self.images, self.ref, stages, record=True) for _ in range(max(1, inflight))]
+            self.graphs = [GraphedPipeline(self.pipe, self.images, self.ref, stages, record=True, stream=(self.lanes[i] if self.lanes else None))
+                           for i in range(max(1, inflight))]
         self.issued = 0
+
+    def _build_segk(self, q0, kpts):
+        """The matcher's real call pattern (localization/multimap3d.py:112-139 -> singlemap3d.py:143-154): per query, for each of
+        the seg_k best-voted landmarks, the keypoints voted to that landmark (all keypoints when they are too few) are matched
+        against that landmark's reference frame — seg_k small ragged pairs, each with its own reference set.  Built once, untimed,
+        from a first recognition of the batch: pair p = (query b, its i-th most voted landmark): query side = that landmark's
+        keypoints (<= 512, >= 32 else the query's 512 best), reference side = a twin set of the query side (make_reference_sets)
+        cut to a seeded length in [600, 1376].  The step then runs extract + recognise as usual and ALL pairs of the batch in ONE
+        grouped produce_matches call (lens0 / lens1: each pair computes its own B = 1 result)."""
+        from pram_amd import weights as Wt
+        K, B, dev = self.segk, self.B, self.dev
+        with torch.no_grad():
+            out = self.pipe.run(self.images, None, stages="er")
+            torch.cuda.synchronize()
+        lm = out["landmark"].cpu()
+        cnt = out["counts"].cpu().tolist()
+        MQ, NR = 512, 1376
+        idx = torch.zeros(B * K, MQ, dtype=torch.long)
+        lens0 = torch.zeros(B * K, dtype=torch.int32)
+        for b in range(B):
+            ids = lm[b, :cnt[b]]
+            fg = ids[ids >= 0]
+            order = torch.bincount(fg).argsort(descending=True)[:K].tolist() if fg.numel() else []
+            for i in range(K):
+                sel = torch.nonzero(ids == order[i]).flatten()[:MQ] if i < len(order) else torch.zeros(0, dtype=torch.long)
+                if sel.numel() < 32:                                  # (the reference's fallback: all keypoints; capped like the secondary shape)
+                    sel = torch.arange(min(MQ, cnt[b]))
+                idx[b * K + i, :sel.numel()] = sel
+                lens0[b * K + i] = sel.numel()
+        self.sk_q = torch.arange(B).repeat_interleave(K).to(dev)
+        self.sk_idx, self.sk_lens0 = idx.to(dev), lens0.to(dev)
+        sub = lambda t: t[self.sk_q[:, None], self.sk_idx]
+        d0, k0, s0 = sub(out["descriptors"]), sub(out["keypoints"]), sub(out["scores"])
+        ref, gt = make_reference_sets(d0, k0, s0, lens0.tolist(), 7000 + q0, n_ref=NR)
+        lens1 = torch.floor(Wt.uniform(11 + q0, "bench/segk/lens1", (B * K,), 600.0, NR + 0.999)).to(torch.int32).to(dev)
+        gt = torch.where(gt < lens1[:, None].long(), gt, torch.full_like(gt, -1))
+        pad0 = torch.arange(MQ, device=dev)[None] >= self.sk_lens0[:, None]
+        gt[pad0] = -1
+        self.sk_ref, self.sk_lens1, self.sk_gt = ref, lens1, gt
+        self.segk_sizes = {"pairs_per_step": B * K, "query_side": [int(lens0.min()), int(lens0.float().mean()), int(lens0.max())],
+                           "reference_side": [int(lens1.min()), int(lens1.float().mean()), int(lens1.max())]}
+
+    def _segk_step(self):
+        from pram_amd.pipeline import QueryPipeline
+        out = self.pipe.run(self.images, None, stages="er")
+        sub = lambda t: t[self.sk_q[:, None], self.sk_idx]      # (torch indexing: this mode's gather is a framework kernel)
+        data = {"descriptors0": sub(out["descriptors"]), "keypoints0": sub(out["keypoints"]), "scores0": sub(out["scores"]),
+                "lens0": self.sk_lens0, "image_shape0": (1, 3, W_IMG, H),
+                "descriptors1": self.sk_ref["descriptors"], "keypoints1": self.sk_ref["keypoints"], "scores1": self.sk_ref["scores"],
+                "lens1": self.sk_lens1, "image_shape1": (1, 3, W_IMG, H)}
+        m = self.matcher.produce_matches(data)
+        self.sk_matches = m["matches0"]
+        return QueryPipeline.pack_record(out)
+
+    def _upload(self):
+        self.dev_u8.copy_(self.host_u8, non_blocking=True)
+        from pram_amd import ops
+        ops.stage_frames(self.dev_u8, self.lut, out=self.images)
 
     def step(self):
         from pram_amd.pipeline import QueryPipeline, gather_records
@@ -496,20 +571,30 @@ class Job:
         i = self.issued
         self.issued += 1
         if self.lanes is None:
+            if self.h2d:
+                self._upload()
             if self.graphs is not None:
                 self.graphs[0].replay()
                 rec = self.graphs[0].record
+            elif self.segk:
+                rec = self._segk_step()
             else:
                 rec = QueryPipeline.pack_record(self.pipe.run(self.images, self.ref, stages=self.stages))
+            self.last_local = rec
             return gather_records(rec, sizes)
         lane = self.lanes[i % len(self.lanes)]
         with torch.cuda.stream(lane):
+            if self.h2d:
+                self._upload()
             if self.graphs is not None:
                 g = self.graphs[i % len(self.graphs)]
                 g.replay()
                 rec = g.record
+            elif self.segk:
+                rec = self._segk_step()
             else:
                 rec = QueryPipeline.pack_record(self.pipe.run(self.images, self.ref, stages=self.stages))
+        self.last_local = rec          # this rank's own records of the step just issued (main(): checked against its slice of the gather)
         if self.world == 1:
             return rec
         # the (tiny) all-gather stays on the one main stream, in step order on every rank: RCCL never sees
@@ -686,6 +771,13 @@ def main():
         dt = max(float(x.item()) for x in allt)
     assert rec.shape[0] == total_per_step, (rec.shape, total_per_step)
     local_rec = rec[q0 - spans[0][0]:q1 - spans[0][0]] if world > 1 else rec
+    # the gather keeps query order: on EVERY rank, rows [q0, q1) of the gathered record are the records this rank computed in the
+    # last step (uneven shards included); one flag per rank, gathered
+    order_ok = bool(torch.equal(local_rec, job.last_local))
+    if world > 1:
+        flags = [None] * world
+        dist.all_gather_object(flags, order_ok)
+        order_ok = all(flags)
     n_matches = int((local_rec[:, :, 4] >= 0).sum().item())
     n_correct = 0
     if do_match:
@@ -741,7 +833,11 @@ def main():
     if rank == 0 and world == 1 and want_alt:
         alt = {}
 
+        only = [x for x in os.environ.get("PRAM_BENCH_ALTS", "").split(",") if x]      # profiling: a subset, in the usual order
+
         def alt_run(name, note, steps_=3, warm_=2, p_split=None, chunk=None, parity_f16=False, **kw):
+            if only and name not in only:
+                return
             cfg = dict(matcher_name=args.matcher, kpts=args.kpts, n_class=args.n_class, stages=args.stages, inflight=inflight,
                        use_graph=False, precision=None, ref_kpts=0, match_kpts=0)
             cfg.update(kw)
@@ -760,6 +856,12 @@ def main():
                 t, _ = j.timed(steps_, warm_, sync_all)
                 hit = ops.x3_range_exceeded(dev) if ops.x3_launched(dev) else False
                 alt[name] = {"queries_per_s": round(Bq * steps_ / t, 2), "ms_per_step": round(t / steps_ * 1e3, 3), "steps": steps_, "what": note}
+                if j.segk:
+                    torch.cuda.synchronize()
+                    ok_ = (j.sk_matches >= 0)
+                    alt[name].update(j.segk_sizes)
+                    alt[name]["matches"] = int(ok_.sum())
+                    alt[name]["matches_correct"] = int(((j.sk_matches == j.sk_gt) & ok_).sum())
                 if hit:
                     alt[name]["x3_range_exceeded"] = True
                 if parity_f16 and not args.no_parity:
@@ -781,6 +883,12 @@ def main():
         alt_run("exact_f32", "same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)", precision="f32")
         alt_run("gml_512x1024", "secondary matcher shape of SURVEY 8(d): the 512 best keypoints of a query against 1024-keypoint reference sets",
                 ref_kpts=1024, match_kpts=512)
+        alt_run("matcher_segk5", "the matcher's real call pattern (localization/multimap3d.py:112-139): extract + recognise, then per query the 5 most "
+                "voted landmarks' keypoint subsets (<= 512) each against its own ragged reference set (600..1376), all 80 pairs of the batch in "
+                "ONE grouped produce_matches call (lens0 / lens1)", segk=5)
+        alt_run("h2d_in_step", "the default step with the reference's frame preparation INSIDE it (loc_by_rec_online.py:86-106): 16 uint8 frames from "
+                "pinned host memory per step (14.7 MB over PCIe on the lane's stream) -> pram_stage_frames_u8 -> the step; `value` itself keeps "
+                "the frames resident, as the benchmark contract asks", h2d=True)
         alt_run("latency_b1", "one query per step, one step at a time, captured hipGraph replayed (the reference's online loop), 512-key attention chunks "
                 "(= python bench.py --latency); ms_per_step = per-query latency", steps_=30, warm_=10, B=1, inflight=1, use_graph=True, chunk=512)
         alt_run("c4", "BASELINE configs[3] shape (CambridgeLandmarks-like): 4096 keypoints, nc161, 8 queries per step, default (split-fp16) path",
@@ -814,6 +922,7 @@ def main():
             "range_guard": {"x3_range_exceeded": bool(range_hit), "split_fp16_kernels_in_step": bool(x3_ran),
                             "policy": "deferred: the status word is read once after the timed region (steps in flight); set = the line is void"},
         }
+        line["config"]["gather_order_verified"] = order_ok
         if world > 1:
             line["per_rank_ms_per_step"] = [round(x, 3) for x in rank_ms]
             line["config"]["host_core_of_rank0"] = core
@@ -832,6 +941,8 @@ def main():
         dist.destroy_process_group()
     if range_hit:
         raise SystemExit("bench.py: the split-fp16 path met an activation beyond its range (range_guard) — the timed steps are void")
+    if not order_ok:
+        raise SystemExit("bench.py: the gathered record does not hold every rank's records at its own query positions")
     if parity is not None and not parity["ok"]:
         raise SystemExit("bench.py: PARITY GATE FAILED (see the 'parity' object of the JSON line)")
 

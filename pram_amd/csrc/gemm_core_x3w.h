@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include "gemm_core_x3.h"
+#include <type_traits>
 
 namespace gemmx3w {
 
@@ -23,6 +24,10 @@ using gemmx3::split4;
 using gemmx3::swz;
 
 constexpr int BK = 32;
+#ifndef PRAM_GEMM_SHADOW
+#define PRAM_GEMM_SHADOW 1      // 1: the 256-row tile loop stages the next chunk inside its MFMA stream (mainloop, "Staging in the shadow")
+#endif
+constexpr bool SHADOW = PRAM_GEMM_SHADOW != 0;
 
 // PRAM_GEMM_ABLATE=4 (profiling only): wave 0 of every workgroup adds the shader-clock cycles it spent per main-loop phase
 // [0] issue + MFMA k-steps  [1] waiting for the chunk's loads (vmcnt)  [2] commit (split + ds_write)  [3] barrier
@@ -240,6 +245,142 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
             step(kt, g0, g1);
             if (kt + 1 < nk) step(kt + 1, g1, g0);
         }
+    } else if constexpr (ABL == 0 && SHADOW) {
+        // "Staging in the shadow" (round 5).  A SIMD runs its two waves almost one at a time (the older wave wins every issue
+        // arbitration: profiles/r05_attn_phases.txt, r02_x3_gemm_phases.txt), so what a wave does outside its MFMA stream is paid
+        // in full: the plain loop below spends ~700 clocks issuing a chunk's eight memory instructions in FRONT of its 48 MFMAs and
+        // ~600 splitting and writing the staged A operand BEHIND them, per wave.  Here both ride inside the stream: the loads of
+        // chunk kt + 1 are issued between the MFMAs of k-step 0 of chunk kt (one A load and one B DMA piece per 32-row block), and
+        // their split / LDS writes between the MFMAs of k-step 1 (one staged quad per block: ~25 vector instructions behind 6 MFMAs,
+        // 1 : 4 by sched_group_barrier — a VOP2 costs a wave 4 clocks, an MFMA 33.5, profiles/r05_mfma_valu_overlap.txt).  Same
+        // MFMA order, same products: bit-identical to the plain loop.
+        static_assert(MI == 4, "one staging piece per 32-row block of the 256-row tile");
+        Regs g;
+        adv(0);
+        issue(0, g);
+        dma(0, 0);
+        commit(0, g);
+        dma_wait();
+        __syncthreads();
+        auto issue_piece = [&](int kt, int p) {
+            if (p == 0) { g.ok = 0u; g.kt = kt; }
+            if constexpr (DMA < 2) {
+                if (p < NA) {
+                    if constexpr (APLANES) { g.ah[p] = la(p, kt, 0); g.al[p] = la(p, kt, 1); }
+                    else g.a[p] = la(p, kt);
+                    g.ok |= (oka(p, kt) ? 1u : 0u) << p;
+                }
+            }
+        };
+        // piece i of the B tile's DMA (dma_tile's i-th round: wave w moves 1-KiB piece w + 8 i), and of A's when it travels that way
+        auto dma_piece = [&](int buf, int kt, int i) {
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            constexpr int NWV = C::NT / 64;
+            {
+                constexpr int PIECES = C::BN / 16;
+                const int piece = wv + NWV * i;
+                if (piece < 2 * PIECES) {
+                    const int plane = piece / PIECES, pc = piece % PIECES;
+                    const int row = pc * 16 + (ln >> 2);
+                    const int slot = (ln & 3) ^ ((row >> 2) & 3);
+                    __builtin_amdgcn_global_load_lds(bptr(row, plane, kt) + slot * 8, (plane ? s.bl[buf] : s.bh[buf]) + pc * 16 * BK, 16, 0, 0);
+                }
+            }
+            if constexpr (DMA >= 2) {
+                constexpr int PIECES = C::BM / 16;
+                const int piece = wv + NWV * i;
+                if (piece < 2 * PIECES) {
+                    const int plane = piece / PIECES, pc = piece % PIECES;
+                    const int row = pc * 16 + (ln >> 2);
+                    const int slot = (ln & 3) ^ ((row >> 2) & 3);
+                    __builtin_amdgcn_global_load_lds(aptr(row, plane, kt) + slot * 8, (plane ? s.al[buf] : s.ah[buf]) + pc * 16 * BK, 16, 0, 0);
+                }
+            }
+        };
+        auto commit_piece = [&](int buf, int p) {
+            if (p >= NA) return;
+            if constexpr (DMA < 2) {
+                if constexpr (APLANES) {
+                    const int row = qrow + C::RQ * p;
+                    uint4 vh = g.ah[p], vl = g.al[p];
+                    if (!((g.ok >> p) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+                    const int off = row * BK + swz(qsl, row) * 8;
+                    *reinterpret_cast<uint4*>(&s.ah[buf][off]) = vh;
+                    *reinterpret_cast<uint4*>(&s.al[buf][off]) = vl;
+                } else {
+                    const int row = arow + C::RA * p;
+                    float4 v = g.a[p];
+                    if (!((g.ok >> p) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else axf(v, p, g.kt);
+                    half4 hi, lo;
+                    split4(v, a_scale, hi, lo, amax);
+                    const int off = row * BK + swz(akq >> 1, row) * 8 + (akq & 1) * 4;
+                    *reinterpret_cast<half4*>(&s.ah[buf][off]) = hi;
+                    *reinterpret_cast<half4*>(&s.al[buf][off]) = lo;
+                }
+            }
+        };
+        // one k-step with a piece of staging work behind each 32-row block's six MFMAs
+        auto kstep_with = [&](int cur, int ks, auto&& piece, int vmem, int valu, int dsw) {
+            const int arow0 = (wm * 32 * MI + r) * BK, brow0 = (wn * 64 + r) * BK;
+            const int slot = swz(2 * ks + h, r) * 8;
+            half8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                bh[ni] = *reinterpret_cast<const half8*>(&s.bh[cur][brow0 + ni * 32 * BK + slot]);
+                bl[ni] = *reinterpret_cast<const half8*>(&s.bl[cur][brow0 + ni * 32 * BK + slot]);
+            }
+            ah[0] = *reinterpret_cast<const half8*>(&s.ah[cur][arow0 + slot]);
+            al[0] = *reinterpret_cast<const half8*>(&s.al[cur][arow0 + slot]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                if (mi + 1 < MI) {
+                    ah[(mi + 1) & 1] = *reinterpret_cast<const half8*>(&s.ah[cur][arow0 + (mi + 1) * 32 * BK + slot]);
+                    al[(mi + 1) & 1] = *reinterpret_cast<const half8*>(&s.al[cur][arow0 + (mi + 1) * 32 * BK + slot]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi & 1], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi & 1], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi & 1], bh[ni], acc[mi][ni], 0, 0, 0);
+                piece(mi);
+                (void)vmem; (void)valu; (void)dsw;
+            }
+        };
+        auto chunk = [&](int kt, auto more_t) {
+            constexpr bool more = decltype(more_t)::value;
+            if constexpr (more) adv(kt + 1);
+            kstep_with(kt & 1, 0, [&](int mi) {
+                if constexpr (more) {
+                    issue_piece(kt + 1, mi);
+                    dma_piece((kt + 1) & 1, kt + 1, mi);
+                    // six MFMAs, the address arithmetic and the two memory instructions of the piece spread behind them
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+                        if (i == 2 || i == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            }, 0, 0, 0);
+            kstep_with(kt & 1, 1, [&](int mi) {
+                if constexpr (more) {
+                    commit_piece((kt + 1) & 1, mi);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        if (i == 5) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    }
+                }
+            }, 0, 0, 0);
+            dma_wait();
+            __syncthreads();
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) chunk(kt, std::true_type{});
+        chunk(nk - 1, std::false_type{});
     } else {
         Regs g;
         adv(0);

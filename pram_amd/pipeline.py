@@ -22,6 +22,49 @@ import torch
 from . import ops
 
 
+_BRANCH = {}      # (device index, main stream id) -> a stream that was MEASURED to run beside that main stream
+
+
+def _branch_stream(device, main: Optional[torch.cuda.Stream] = None) -> torch.cuda.Stream:
+    """A stream for the forked branch (recognise || match) that really runs beside ``main`` (default: the current stream).
+
+    ROCm multiplexes a process's HIP streams onto a few hardware queues by creation order, so a stream created after a handful of
+    others can share its queue with the stream it is meant to overlap: the two branches of the step then run one after the other
+    and nothing says so (measured: one-query latency 3.9 -> 5.1 ms = the serial sum, in a process that had created ~25 streams
+    before; a high-priority stream made it 10.4; profiles/r05_stream_queue_collision.txt).  So the choice is measured, once per
+    (device, main stream): two ~0.15 ms spin kernels (torch.cuda._sleep), one per stream; a candidate whose pair takes about the
+    time of one is kept.  Placement is for speed only; any stream gives the same results."""
+    import time
+    dev = torch.device(device)
+    main = main or torch.cuda.current_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
+    if key in _BRANCH:
+        return _BRANCH[key]
+
+    def spin(cands, cycles=300_000):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for st in cands:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    spin([main])
+    one = min(spin([main]) for _ in range(3))
+    best, best_t = None, float("inf")
+    for _ in range(8):
+        c = torch.cuda.Stream(device=dev)
+        spin([main, c])
+        t = min(spin([main, c]) for _ in range(2))
+        if t < best_t:
+            best, best_t = c, t
+        if t < 1.5 * one:
+            break
+    _BRANCH[key] = best
+    return best
+
+
 class QueryPipeline:
     """guard: range guard of the split-fp16 path for one run() (ops.guarded_call): "fallback" (default) reads the device status
     word once after the last launch — the one host synchronisation of a run — and re-runs the batch on the exact-fp32 kernels
@@ -38,7 +81,7 @@ class QueryPipeline:
         self.overlap_below = overlap_below      # batches smaller than this run recognise || match on two streams
         self.guard = guard
         self.match_keypoints = int(match_keypoints)
-        self._side = None
+        self._side, self._side_main = None, None
 
     def _match(self, ex, ref, W, H):
         kpts, scores, counts, desc = ex['keypoints'], ex['scores'], ex['counts'], ex['descriptors']
@@ -90,8 +133,8 @@ class QueryPipeline:
         forked = self._forks(B, ref, stages)
         if forked:
             main = torch.cuda.current_stream(images.device)
-            if self._side is None or self._side.device != images.device:
-                self._side = torch.cuda.Stream(device=images.device)
+            if self._side is None or self._side.device != images.device or self._side_main != main.cuda_stream:
+                self._side, self._side_main = _branch_stream(images.device, main), main.cuda_stream
             self._side.wait_stream(main)                 # extraction results are ready for the side stream
             with torch.cuda.stream(self._side):
                 m = self._match(ex, ref, W, H)
@@ -170,14 +213,16 @@ class GraphedPipeline:
     re-issue for callers that keep several steps in flight and check ``ops.x3_range_exceeded()`` themselves."""
 
     def __init__(self, pipe: QueryPipeline, images: torch.Tensor, ref: Optional[Dict[str, torch.Tensor]] = None, stages: str = "erm",
-                 warmup: int = 2, record: bool = False, split: Optional[bool] = None):
+                 warmup: int = 2, record: bool = False, split: Optional[bool] = None, stream: Optional[torch.cuda.Stream] = None):
         self.pipe, self.stages = pipe, stages
         self.images = images.clone()
         self.ref = None if ref is None else {k: v.clone() for k, v in ref.items()}
         self.with_record = record
         self.record = None
         self._ws = {}                 # this graph's private scratch (ops.workspace_scope): never shared, never regrown by others
-        self._side = torch.cuda.Stream(device=images.device) if pipe.overlap_below > images.shape[0] else None
+        # stream: the stream the graph will be REPLAYED on (default: the current one) — the forked branch gets a stream measured to
+        # run beside it (_branch_stream)
+        self._side = _branch_stream(images.device, stream) if pipe.overlap_below > images.shape[0] else None
         # A step that forks (recognise || match, small batches) is captured as FOUR graphs — extract | match | recognise | record —
         # replayed on two streams: the runtime issues the branches of ONE hipGraph one after the other (measured: a two-branch graph
         # of 2 x 150 kernels replays in 838 us, the same 300 in one chain in 499 us; in the traced step the recogniser's first kernel
@@ -244,14 +289,16 @@ class GraphedPipeline:
 
     def _run_eager(self):
         # the forked branch runs on a side stream owned by THIS graph (the pipeline's own side stream keeps serving eager runs)
-        saved, self.pipe._side = self.pipe._side, self._side
+        dev = self.images.device
+        saved = (self.pipe._side, self.pipe._side_main)
+        self.pipe._side, self.pipe._side_main = self._side, torch.cuda.current_stream(dev).cuda_stream
         try:
             out = self.pipe.run(self.images, self.ref, self.stages, guard="deferred")
             if self.with_record:
                 self.record = QueryPipeline.pack_record(out)
             return out
         finally:
-            self._side, self.pipe._side = self.pipe._side, saved
+            self.pipe._side, self.pipe._side_main = saved
 
     def replay(self) -> Dict[str, torch.Tensor]:
         """Re-issue the captured step on the current stream with the inputs already in the captured buffers; no synchronisation,

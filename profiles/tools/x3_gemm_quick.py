@@ -1,0 +1,32 @@
+"""x3 token GEMM at the step's shapes: time and a bit checksum of the output (variants that only move work must print the same sums).
+    python profiles/tools/x3_gemm_quick.py"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from pram_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+out = []
+for m, k0, k1, n in ((32768, 256, 0, 768), (32768, 256, 256, 512), (32768, 512, 0, 256), (65536, 256, 0, 768), (65536, 256, 256, 512), (65536, 512, 0, 256)):
+    x = torch.randn(m, k0, generator=g).to(dev)
+    x2 = torch.randn(m, k1, generator=g).to(dev) if k1 else None
+    w = (torch.randn(n, k0 + k1, generator=g) / (k0 + k1) ** 0.5).to(dev)
+    b = (torch.randn(n, generator=g) * 0.1).to(dev)
+    f = lambda: ops.linear(x, w, b, x2=x2, precision="x3")
+    for _ in range(10):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30):
+        y = f()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 30 * 1e3
+    cs = int(y.view(torch.int32).to(torch.int64).sum().item())
+    out.append(f"{m}x{k0}+{k1}x{n}: {us:.1f} us {2.0 * m * (k0 + k1) * n / us / 1e6:.0f} TF #{cs & 0xffffff:06x}")
+print(" | ".join(out))

@@ -78,6 +78,39 @@ def test_bench_spawns_its_own_ranks_and_shards_unevenly(hip_lib):
     assert abs(d["value"] - 3 * 2 / (d["ms_per_step"] * 2e-3)) < 0.05 * d["value"]
 
 
+@pytest.mark.parametrize("total", [64, 65])
+def test_bench_eight_ranks_on_one_device(hip_lib, total):
+    """BASELINE configs[2]'s launch shape with the one-GPU test hook: `bench.py --gpus 8 --batch-total 64 | 65` starts eight ranks
+    (all on GPU 0, gloo), shards 8 x 8 / 9 + 7 x 8 queries, and every rank finds its own records at its own query positions of the
+    gathered record (config.gather_order_verified); the line carries one time per rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PRAM_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch-total", str(total),
+                        "--cpu-queries", "0", "--no-parity"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    want = [9] + [8] * 7 if total == 65 else 8
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["queries_per_step"] == total
+    assert d["config"]["queries_per_gpu_per_step"] == want and d["config"]["gather_order_verified"] is True
+    assert len(d["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) < 1e-3 * d["ms_per_step"] + 1e-3
+    assert abs(d["value"] - total * 2 / (d["ms_per_step"] * 2e-3)) < 0.05 * d["value"]
+
+
+def test_bench_one_rank_through_the_launcher_equals_the_plain_run(hip_lib):
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (how the driver starts N > 1) measures what `python bench.py`
+    measures: same line, value within the run-to-run spread."""
+    args = ["--gpus", "1", "--steps", "10", "--warmup", "4", "--cpu-queries", "0", "--no-parity", "--alt", "off"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PRAM_BENCH_ONE_DEVICE")}
+    a = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr + b.stderr)[-3000:]
+    da, db = _last_json(a.stdout), _last_json(b.stdout)
+    assert da["n_gpus"] == db["n_gpus"] == 1 and da["config"]["queries_per_step"] == db["config"]["queries_per_step"] == 16
+    assert abs(da["value"] - db["value"]) < 0.03 * da["value"], (da["value"], db["value"])
+
+
 def test_bench_refuses_more_gpus_than_visible(hip_lib):
     import torch
     n = torch.cuda.device_count() + 1
