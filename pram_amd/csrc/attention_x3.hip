@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     // (A fused variant that parked its chunks like MODE 2 and folded them after the last tile — no spill — was dropped: compiled
     // with two-part probabilities it returned, on ~1 wave in 2500, one output register with the earlier chunks' share missing in
     // lanes 48..63; inputs in memory were right, draining every counter before the fold did not help, the cause was not found.
-    // tests/test_gpu_round3.py::test_x3_attention_many_workgroups_every_mode repeats the launch that showed it.)
+    // tests/test_gpu_guard_chunks_mlp.py::test_x3_attention_many_workgroups_every_mode repeats the launch that showed it.)
     float l_tot2 = -INFINITY;
     float o_tot[2][MODE == 1 ? 16 : 1];
     if constexpr (MODE == 1) {

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
 // the nine taps read their A fragments from that window at shifted pixel rows.  Only the weights still move per chunk (LDS-DMA).
 // A: 43.5 KB per stage x 2 (the next slab's window is requested at the slab's first tap and written at its last), B: 32 KB x 2.
 // K is walked slab by slab with the taps innermost and every accumulator sees lo.hi, hi.lo, hi.hi per 16-deep step — the order
-// of conv_x3w_kernel: the two kernels agree bit for bit (tests/test_gpu_round3.py::test_conv3x3_halo_equals_chunked).
+// of conv_x3w_kernel: the two kernels agree bit for bit (tests/test_gpu_guard_chunks_mlp.py::test_conv3x3_halo_equals_chunked).
 namespace halo {
 constexpr int TH = 8, TW = 32, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;      // 340 window pixels
 constexpr int BK = 32, NT = 512;
@@ -1054,7 +1054,7 @@ extern "C" int pram_nhwc_to_nchw_f32(const float* in, float* out, int batch, int
 // channel, its 72 weights (two planes) stay in registers for the kernel's life and a select zeroes them for the k-steps of the
 // other groups.  out[pixel][channel]: lanes are channels, a store instruction writes 128 contiguous bytes per pixel.
 // fp32-class (three fp16 products, fp32 accumulation), not the fp32 FMA chain of gconv3x3_kernel: the two agree to ~3e-7
-// relative (tests/test_gpu_round4.py::test_grouped_conv_on_the_matrix_pipe).
+// relative (tests/test_gpu_precision_conv_fusions.py::test_grouped_conv_on_the_matrix_pipe).
 namespace {
 namespace gx {
 constexpr int TH = 8, TW = 16, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;      // 180 window pixels

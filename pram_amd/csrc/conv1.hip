@@ -13,7 +13,7 @@
 //       window planes (70 KB) are both resident: 54 MFMAs per wave between two barriers, accumulators kept across the halves.
 // Arithmetic: conv1a runs here as split-fp16 products like every other layer (the stand-alone conv1a is the exact-fp32 MFMA kernel
 // only because its 4-channel input does not fit the generic split-fp16 tiles), conv1b's K order is (half, tap, channel) — the order
-// of conv_x3_kernel.  fp32-class results, not bit-identical to the two-kernel path (tests/test_gpu_round4.py::test_fused_conv1).
+// of conv_x3_kernel.  fp32-class results, not bit-identical to the two-kernel path (tests/test_gpu_precision_conv_fusions.py::test_fused_conv1).
 #include <stdlib.h>
 #include "gemm_core.h"
 #include "gemm_core_x3.h"

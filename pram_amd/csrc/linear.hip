@@ -51,7 +51,7 @@ struct LinArgs {
 // t >= 0, s below.  |t ds| <= 7.5e-8 over the whole line — the class of erff's own rounding times t — for seven multiply-adds,
 // one v_exp and four other instructions, where erff costs ~31: the GELU of the hidden layer is applied inside a GEMM's staging
 // path, where every VALU instruction competes with the split arithmetic.  Beyond |t| = 6 the tail is held at s(6) = 1e-9.
-// tests/test_gpu_round3.py pins it against an fp64 GELU on a dense grid.
+// tests/test_gpu_guard_chunks_mlp.py pins it against an fp64 GELU on a dense grid.
 __device__ __forceinline__ float gelu_erf(float t) {
     const float a = fminf(fabsf(t), 6.0f);
     float q = fmaf(-3.327738795633195e-06f, a, 1.992317265830934e-06f);
