@@ -37,6 +37,22 @@ def test_bench_one_gpu_line(hip_lib):
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches_per_step"] == 33
 
 
+def test_bench_alt_matcher_pattern_and_upload_in_step(hip_lib):
+    """Two of the `alt` configurations on a small batch: the matcher's real call pattern (seg_k ragged pairs per query in one grouped
+    call: every reported match is the planted twin) and the frame upload inside the step (uint8 frames from pinned host memory +
+    pram_stage_frames_u8)."""
+    env = dict(os.environ, PRAM_BENCH_ALTS="matcher_segk5,h2d_in_step")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--batch-per-gpu", "2", "--cpu-queries", "0",
+                        "--no-parity", "--alt", "on"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    alt = _last_json(r.stdout)["alt"]
+    assert set(alt) == {"matcher_segk5", "h2d_in_step"} and not any("error" in v for v in alt.values()), alt
+    sk = alt["matcher_segk5"]
+    assert sk["pairs_per_step"] == 10 and sk["query_side"][2] <= 512 and 600 <= sk["reference_side"][0] <= sk["reference_side"][2] <= 1376
+    assert sk["matches"] > 500 and sk["matches_correct"] >= 0.99 * sk["matches"]
+    assert alt["h2d_in_step"]["queries_per_s"] > 0
+
+
 def test_bench_latency_mode_line(hip_lib):
     """`--latency`: one query per step, nothing in flight, the step replayed from captured graphs on two streams, 512-key attention
     chunks (split launches); the parity gate runs on the same arithmetic."""
