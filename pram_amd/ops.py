@@ -878,7 +878,7 @@ def _workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
 
 
 # plans of one Sinkhorn call: at most this many bytes per group of pairs (0 = one call for the whole batch)
-sinkhorn_group_bytes = int(_os.environ.get("PRAM_SINKHORN_GROUP_MB", "0")) << 20
+sinkhorn_group_bytes = int(_os.environ.get("PRAM_SINKHORN_GROUP_MB", "135")) << 20      # 0: one group (see sinkhorn_match)
 
 
 def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, threshold: float,
@@ -899,8 +899,13 @@ def sinkhorn_match(dist: torch.Tensor, bin_score: torch.Tensor, iters: int, thre
     # The 20 iterations stream the whole [m + 1, n + 1] plan of every pair: a group of pairs whose plans fit the 256 MB infinity
     # cache together iterates out of it (35 us per pair and call instead of 67 from HBM, profiles/r02_sinkhorn_batch.txt), so a
     # large batch runs group after group — same kernels, every pair its own rows: results do not depend on the grouping.
+    # Default (round 5, profiles/r05_sinkhorn_group_ab.txt): groups of <= 135 MB (8 pairs of 2049 x 2049: +0.7 % queries/s in three
+    # alternations on one box), but only when a group still holds at least four pairs — at 4097 x 4097 (67 MB per pair) two-pair
+    # groups double the call's 42 dependent launches for nothing (-0.8 %).
     per_pair = (M + 1) * ((N + 4) // 4 * 4) * 4
-    group = B if sinkhorn_group_bytes <= 0 else max(1, min(B, sinkhorn_group_bytes // max(per_pair, 1)))
+    group = B
+    if sinkhorn_group_bytes > 0 and sinkhorn_group_bytes // max(per_pair, 1) >= 4:
+        group = max(1, min(B, sinkhorn_group_bytes // max(per_pair, 1)))
     for b0 in range(0, B, group):
         b1 = min(B, b0 + group)
         nb = b1 - b0
