@@ -80,6 +80,20 @@ __device__ __forceinline__ void dma_tile(_Float16* lds_hi, _Float16* lds_lo, Row
     }
 }
 
+// round i of dma_tile alone (wave w moves piece w + NWAVES i): for loops that issue a tile's DMA piecewise inside their MFMA stream
+template <int ROWS, int NWAVES, class RowPtr>
+__device__ __forceinline__ void dma_piece(_Float16* lds_hi, _Float16* lds_lo, RowPtr& rowptr, int i) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PIECES = ROWS / 16;
+    const int piece = wave + NWAVES * i;
+    if (piece < 2 * PIECES) {
+        const int plane = piece / PIECES, pc = piece % PIECES;
+        const int row = pc * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        __builtin_amdgcn_global_load_lds(rowptr(row, plane) + slot * 8, (plane ? lds_lo : lds_hi) + pc * 16 * BK, 16, 0, 0);
+    }
+}
+
 // APLANES = false: ALoad(p, kt) -> raw float4 A[row = tid/8 + RA p][kt*32 + (tid%8)*4 ..+3] (fp32, split here)
 // APLANES = true : ALoad(p, kt, plane) -> raw uint4 plane[row = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7]
 // BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7];  *Ok: predicates;  Adv as gemm_core_x3.h
