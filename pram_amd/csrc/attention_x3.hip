@@ -22,6 +22,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -31,7 +32,25 @@ constexpr int D = 64, QW = 32, NW = 4, BQ = QW * NW, BKV = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3::ACT_SCALE)
 constexpr float LAZY_T = 8.0f;          // lazy running maximum: it follows the row maximum only when left behind by more than 2^8
-constexpr int MAXG = 7;                 // leading MFMA groups of a tile's score phase that carry the row maximum (4 vector instructions each)
+#ifndef AX_XPRIO
+#define AX_XPRIO 1
+#endif
+// tile-loop form per launch shape (see the kernel): 1 = vector / matrix phases, 0 = interleaved.  Defaults as measured
+// (profiles/r05_attn_phases_ab.txt); the macros exist for that A/B.
+#ifndef AX_STYLE4
+#define AX_STYLE4 0      // 128-row workgroups, one chunk (grids that do not fill the chip)
+#endif
+#ifndef AX_STYLE8
+#define AX_STYLE8 1      // 256-row workgroups
+#endif
+#ifndef AX_STYLEC
+#define AX_STYLEC 1      // key chunks (fused and split)
+#endif
+constexpr int SPREAD_MAXG = 7;          // interleaved form: leading MFMA groups of a tile's score phase that carry the row maximum
+#ifndef AX_ABL
+#define AX_ABL 0      // profiling only (results are garbage): 1 no soft-max, 2 no MFMA, 3 no fragment reads, 4 soft-max of the first tile only
+#endif
+
 constexpr float P_EXP_SHIFT = 7.0f;     // probabilities carried as 2^7 p, at most 2^15 with the lazy maximum LAZY_T behind
 
 struct ArgsX {
@@ -131,7 +150,9 @@ static __device__ unsigned long long attn_prof[4096][4];
 static __device__ unsigned long long attn_phase[8][4];      // per wave of the workgroup: shader clocks per tile phase, summed over workgroups
 #endif
 
-template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW>
+constexpr bool style_phases(int mode, int nwv) { return mode != 0 ? AX_STYLEC : nwv == NW ? AX_STYLE4 : AX_STYLE8; }
+
+template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW, bool PHASES = style_phases(MODE, NWV)>
 __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe_kernel(ArgsX p) {
 #ifdef PRAM_PROFILING
     const unsigned long long prof_t0 = wall_clock64(), prof_c0 = __builtin_readcyclecounter();
@@ -192,23 +213,38 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
 
     const int lrow = tid >> 3, lseg = tid & 7;
     half8 krh[PPN], krl[PPN], vrh[PPN], vrl[PPN];
-    auto gload_k = [&](int kt) {
+    // Staging addresses as a uniform base (scalar registers) plus a 32-bit byte offset per thread: one or two vector instructions per
+    // tile instead of the 64-bit multiply-adds of a per-thread pointer (they sat in the vector phase, which bounds the tile loop).
+    // min(row, klen - 1) * ldk == min(row * ldk, (klen - 1) * ldk): the clamp of the last tile costs one v_min.
+    const char* const kh_b = reinterpret_cast<const char*>(p.kh + koff);
+    const char* const kl_b = reinterpret_cast<const char*>(HI ? p.kh : p.kl + koff);
+    const char* const vh_b = reinterpret_cast<const char*>(p.vh + voff);
+    const char* const vl_b = reinterpret_cast<const char*>(HI ? p.vh : p.vl + voff);
+    unsigned kofs[PPN], vofs[PPN];
+#pragma unroll
+    for (int pp = 0; pp < PPN; ++pp) {
+        kofs[pp] = ((unsigned)(lrow + SROWS * pp) * (unsigned)p.ldk + lseg * 8) * 2u;
+        vofs[pp] = ((unsigned)(lrow + SROWS * pp) * (unsigned)p.tv + lseg * 8) * 2u;
+    }
+    const unsigned klast = ((unsigned)(klen - 1) * (unsigned)p.ldk + lseg * 8) * 2u;
+    const unsigned ktile_bytes = (unsigned)BKV * (unsigned)p.ldk * 2u;
+    auto gload_k = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int pp = 0; pp < PPN; ++pp) {
-            const size_t kc = (size_t)min(kt * BKV + lrow + SROWS * pp, klen - 1);
-            krh[pp] = *reinterpret_cast<const half8*>(p.kh + koff + kc * p.ldk + lseg * 8);
-            if constexpr (!HI) krl[pp] = *reinterpret_cast<const half8*>(p.kl + koff + kc * p.ldk + lseg * 8);
+            const unsigned o = min(kofs[pp] + (unsigned)kt * ktile_bytes, klast);
+            krh[pp] = *reinterpret_cast<const half8*>(kh_b + o);
+            if constexpr (!HI) krl[pp] = *reinterpret_cast<const half8*>(kl_b + o);
         }
     };
-    auto gload_v = [&](int kt) {
+    auto gload_v = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int pp = 0; pp < PPN; ++pp) {
-            const size_t vo = voff + (size_t)(lrow + SROWS * pp) * p.tv + kt * BKV + lseg * 8;
-            vrh[pp] = *reinterpret_cast<const half8*>(p.vh + vo);
-            if constexpr (!HI) vrl[pp] = *reinterpret_cast<const half8*>(p.vl + vo);
+            const unsigned o = vofs[pp] + (unsigned)kt * (BKV * 2u);
+            vrh[pp] = *reinterpret_cast<const half8*>(vh_b + o);
+            if constexpr (!HI) vrl[pp] = *reinterpret_cast<const half8*>(vl_b + o);
         }
     };
-    auto lstore_k = [&](int buf) {
+    auto lstore_k = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int pp = 0; pp < PPN; ++pp) {
             const int row = lrow + SROWS * pp;
@@ -217,7 +253,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             if constexpr (!HI) *reinterpret_cast<half8*>(&s.kl[buf][off]) = krl[pp];
         }
     };
-    auto lstore_v = [&](int buf) {
+    auto lstore_v = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int pp = 0; pp < PPN; ++pp) {
             const int row = lrow + SROWS * pp;
@@ -228,7 +264,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     };
 
     struct KFrag { half8 h0, h1, l0, l1; };
-    auto kload = [&](int buf, int c, KFrag& f) {
+    auto kload = [&](int buf, int c, KFrag& f) __attribute__((always_inline)) {
+#if AX_ABL == 3
+        asm volatile("" : "=v"(f.h0), "=v"(f.h1), "=v"(f.l0), "=v"(f.l1));
+        return;
+#endif
         const int slot = ((2 * c + h) ^ ((r >> 1) & 7)) << 3;
         f.h0 = *reinterpret_cast<const half8*>(&s.kh[buf][r * D + slot]);
         f.h1 = *reinterpret_cast<const half8*>(&s.kh[buf][(32 + r) * D + slot]);
@@ -237,7 +277,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
             f.l1 = *reinterpret_cast<const half8*>(&s.kl[buf][(32 + r) * D + slot]);
         }
     };
-    auto kmma = [&](f32x16 (&st)[2], int c, const KFrag& f) {
+    auto kmma = [&](f32x16 (&st)[2], int c, const KFrag& f) __attribute__((always_inline)) {
+#if AX_ABL == 2
+        asm volatile("" :: "v"(f.h0), "v"(f.h1), "v"(f.l0), "v"(f.l1));
+        return;
+#endif
         if constexpr (!HI) {
             st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, qh[c], st[0], 0, 0, 0);
             st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, qh[c], st[1], 0, 0, 0);
@@ -248,7 +292,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, qh[c], st[1], 0, 0, 0);
     };
     struct VFrag { half8 h0, h1, l0, l1; };
-    auto vload = [&](int buf, int t, int u, VFrag& f) {
+    auto vload = [&](int buf, int t, int u, VFrag& f) __attribute__((always_inline)) {
+#if AX_ABL == 3
+        asm volatile("" : "=v"(f.h0), "=v"(f.h1), "=v"(f.l0), "=v"(f.l1));
+        return;
+#endif
         const int slot = ((t * 4 + u * 2 + h) ^ ((r >> 1) & 7)) << 3;
         f.h0 = *reinterpret_cast<const half8*>(&s.vth[buf][r * BKV + slot]);
         f.h1 = *reinterpret_cast<const half8*>(&s.vth[buf][(32 + r) * BKV + slot]);
@@ -284,20 +332,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     }
     // The workspace addresses are recomputed where they are used, behind an opaque zero: hoisted out of the tile loop they would be
     // four more registers live across it — spilled, and reloaded with the round trip exposed at every chunk end.
-    auto part_ptr = [&](int c) -> float* {
+    auto part_ptr = [&](int c) __attribute__((always_inline)) -> float* {
         int z = 0;
         asm volatile("" : "+v"(z));
         const size_t row = (size_t)b * p.m_max + min(qt * BQV + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
         return p.part_o + ((size_t)c * p.batch * p.m_max + row) * (p.heads * D) + head * D;
     };
-    auto part_lse = [&](int c) -> float* {
+    auto part_lse = [&](int c) __attribute__((always_inline)) -> float* {
         int z = 0;
         asm volatile("" : "+v"(z));
         const size_t li = ((size_t)b * p.heads + head) * p.m_max + min(qt * BQV + wave * QW + (int)(threadIdx.x & 31) + z, p.m_max - 1);
         return p.part_l + (size_t)c * p.batch * p.heads * p.m_max + li;
     };
     // end of a key chunk inside the walk (MODE 1 / 2): normalise it, fold it (1) or park it (2), start afresh
-    auto chunk_end = [&](int c) {
+    auto chunk_end = [&](int c) __attribute__((always_inline)) {
         const float l_c = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;      // undoes the 2^14 of P (carried by l_c) and the scale of V
         const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
@@ -328,7 +376,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         l_run = 0.f;
     };
     // after the last tile: the last chunk normalised in place (oacc), l_tot2 = its log2-sum-exp; MODE 1 then folds it into the total
-    auto finish = [&]() {
+    auto finish = [&]() __attribute__((always_inline)) {
         const float l_c = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;
         const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
@@ -349,7 +397,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     };
     // O *= alpha, between the two matrix phases of a tile; skipped when no lane's running maximum moved (alpha is exactly 1 on
     // almost every tile: the maximum is lazy, see softmax_a)
-    auto rescale = [&](float alpha) {
+    auto rescale = [&](float alpha) __attribute__((always_inline)) {
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) == 0) return;
 #pragma unroll
         for (int dn = 0; dn < 2; ++dn)
@@ -364,7 +412,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     //   part A (beside S_{j+1} = K_{j+1} Q^T): row maximum, p = 2^(s c + shift) left in place of the scores       ~22 clocks per MFMA
     //   part B (beside O += V_j P_j): per 16-key quarter, right in front of the MFMAs that take them: fp16 hi parts
     //          (v_cvt_pk), lo parts (v_fma_mix), row sums                                                          ~19 clocks per MFMA
-    auto softmax_a = [&](f32x16 (&st)[2]) -> float {
+    auto softmax_a = [&](f32x16 (&st)[2]) __attribute__((always_inline)) -> float {
         float tmax = st[0][0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, st[0][e]);
@@ -391,7 +439,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     // (kept as four separate packed pairs: taking the fp16 halves back out of an int4 / half8 vector for v_fma_mix made this
     // compiler read every pair's hi part from element 0 — profiles/r05_x3_attention_valu_diet.txt)
     struct Hi4 { half2_t v[4]; };
-    auto hi_parts = [&](int t, int u, f32x16 (&st)[2], float& psum) -> Hi4 {
+    auto hi_parts = [&](int t, int u, f32x16 (&st)[2], float& psum) __attribute__((always_inline)) -> Hi4 {
         Hi4 hi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -400,222 +448,482 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
         }
         return hi;
     };
-    auto pack4 = [&](const Hi4& x) -> half8 {
+    auto pack4 = [&](const Hi4& x) __attribute__((always_inline)) -> half8 {
         return (half8){x.v[0][0], x.v[0][1], x.v[1][0], x.v[1][1], x.v[2][0], x.v[2][1], x.v[3][0], x.v[3][1]};
     };
-    // part B + P V of one tile, written in the order it is meant to issue (the sched_group_barriers behind the call pin it): per
-    // 16-key quarter the four products that take P_hi, each followed by one element pair's lo parts (v_fma_mixlo / mixhi) and its
-    // sum; then the two products that take P_lo, followed by the row-sum updates and the NEXT quarter's hi parts.
-    // va / vb: the V^T fragments of the first two quarters, already requested.
-    auto pv_b = [&](int vbuf, f32x16 (&st)[2], float alpha, VFrag& va, VFrag& vb) {
-        float ps4[4] = {0.f, 0.f, 0.f, 0.f}, psum = 0.f;
-        Hi4 hi = hi_parts(0, 0, st, psum);
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int t = qd >> 1, u = qd & 1;
-            VFrag& f = u ? vb : va;
-            Hi4 lo;
-            float pair[4];
-            auto lo_pair = [&](int j) {
-                if constexpr (PSPLIT) {
-                    const float p0 = st[t][8 * u + 2 * j], p1 = st[t][8 * u + 2 * j + 1];
-                    // lo = fp16(p - hi) as ONE instruction per element: fma(p, 1, -hi) with the 1 hidden from the optimiser selects
-                    // v_fma_mixlo / mixhi_f16 (hi read as fp16 from its half of the packed register); a plain p - (float)hi would be
-                    // convert, subtract, convert.  Same value bit for bit (the difference is exact in fp32).
-                    const half2_t hk = hi.v[j];
-                    lo.v[j] = (half2_t){(_Float16)__builtin_fmaf(p0, one, -(float)hk[0]), (_Float16)__builtin_fmaf(p1, one, -(float)hk[1])};
-                    pair[j] = p0 + p1;
-                }
-            };
-            if constexpr (!HI) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, pack4(hi), oacc[0], 0, 0, 0);
-                lo_pair(0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, pack4(hi), oacc[1], 0, 0, 0);
-                lo_pair(1);
-            }
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(hi), oacc[0], 0, 0, 0);
-            lo_pair(2);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(hi), oacc[1], 0, 0, 0);
-            lo_pair(3);
-            Hi4 nhi = hi;
-            if (qd < 3) nhi = hi_parts((qd + 1) >> 1, (qd + 1) & 1, st, psum);
-            if constexpr (PSPLIT) {
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(lo), oacc[0], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ps4[j] += pair[j];
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(lo), oacc[1], 0, 0, 0);
-            }
-            hi = nhi;
-            if (qd == 0) vload(vbuf, 1, 0, va);       // this quarter is through with va / vb: the fragments of quarter qd + 2
-            if (qd == 1) vload(vbuf, 1, 1, vb);
-        }
-        if constexpr (PSPLIT) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-        l_run = fmaf(l_run, alpha, psum);
-    };
-
-    // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own  (tile numbers relative to t0, which is even: the
-    // stage parity of a tile is that of its absolute number)
-    gload_k(t0);
-    lstore_k(0);
-    gload_v(t0);
-    if (t0 + 1 < nkt) gload_k(t0 + 1);
-    lstore_v(0);
-    if (t0 + 1 < nkt) lstore_k(1);
-    __syncthreads();
-    f32x16 sa[2], sb[2];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { sa[0][e] = 0.f; sa[1][e] = 0.f; }
-    if (wave_active) {
-        KFrag fa, fb;
-        kload(0, 0, fa);
-        kload(0, 1, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        kmma(sa, 0, fa);
-        kload(0, 2, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        kmma(sa, 1, fb);
-        kload(0, 3, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        kmma(sa, 2, fa);
-        kmma(sa, 3, fb);
-    }
-    // tile 0's K stage is rewritten (K_2) at the END of the first loop pass, before that pass's barrier: every wave must be done
-    // reading K_0 first
-    if (t0 + 2 < nkt) __syncthreads();
-
 #ifdef PRAM_PROFILING
-    // shader clocks per phase of a tile, summed over the tile loop: [0] loads issued + scores of tile j+1 interleaved with the
-    // soft-max of tile j, [1] P V, [2] the staged tiles written to LDS (waits for the loads), [3] barrier
+    // shader clocks per phase of a tile, summed over the tile loop.  Phases form: [0] V phases, [1] the barrier behind them, [2] X phases,
+    // [3] the barrier behind them.  Interleaved form: [0] scores of tile j+1 beside the soft-max of tile j, [1] P V, [2] the staged tiles
+    // written to LDS (waits for the loads), [3] barrier
     unsigned long long prof_ts[5] = {0, 0, 0, 0, 0}, prof_ph[4] = {0, 0, 0, 0};
 #define PROF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); prof_ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PROF_STAMP(i) do { } while (0)
 #endif
-    // tile j (not the last): S_{j+1} = K_{j+1} Q^T interleaved with softmax(S_j), then O += V_j P_j; K_{j+2} and V_{j+1} staged
-    auto mid = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
-        const int kbuf = (j + 1) & 1, vbuf = j & 1;
-        const bool more_k = j + 2 < nkt;
-        PROF_STAMP(0);
-        gload_v(j + 1);
-        if (more_k) gload_k(j + 2);
-        if (wave_active) {
+    // ---- The tile loop in PHASES (round 5, second step; the form of every launch that puts two waves on a SIMD).  A SIMD serves
+    // its two waves with STRICT priority for the older one on each pipe, but an MFMA-only wave and a vector-only wave overlap almost
+    // perfectly whichever is older (profiles/r05_mfma_valu_two_waves.txt: 33.0 clocks per MFMA beside 8.2 per vector instruction,
+    // against 32.0 / 6.9 alone; two MFMA streams: the younger gets NOTHING until the older is through).  A tile has 48 MFMAs and
+    // ~190 vector instructions per wave — four per MFMA, exactly what that overlap carries.  So a tile is cut into
+    //   V_j : soft-max of S_j -> P_j (hi, lo parts, row sums; the rare rescale of O), the staged K / V tiles written to LDS, the
+    //         next ones requested                                                                            (no MFMA)
+    //   X_j : O += V_j P_j and S_{j+1} = K_{j+1} Q^T                                  (48 MFMAs = 1 608 clocks, no vector work)
+    // with a barrier behind each, and the younger half of an eight-wave workgroup (waves 4-7, the SIMD partners of waves 0-3) runs
+    // the SAME sequence one phase later: while one wave of a SIMD multiplies, its partner does its vector work.
+    //   phase        ... 2j            2j+1          2j+2 ...
+    //   waves 0-3        V_j           X_j           V_{j+1}
+    //   waves 4-7        X_{j-1}       V_j           X_j
+    // The wave in X raises its priority (s_setprio 1): left to age order the older wave won BOTH its phases and waited ~1 300 clocks
+    // per tile at the barriers for its partner (no gain over the interleaved form); with it the two take equal time (-4 %).
+    // Measured (profiles/r05_attn_phases_ab.txt, 32 x 2048 keys): interleaved 391 us, phases 391, + priority 376, + 32-bit staging
+    // offsets 364; X alone (soft-max of the first tile only) 266 us, V alone (no MFMA) 108 us: about 40 % of the vector work is
+    // hidden, and what is left scales with the vector ISSUE CLOCKS of a tile whichever wave carries them — moving a quarter or half
+    // of the conversions into the head of X, a second K fragment slot, priority for the younger half only: no gain, not kept.
+    // LDS: K_t is read in phases 2t-1 (older half) and 2t (younger), V_t in 2t+1 and 2t+2; every thread stages its 16-byte share of
+    // each plane; the older half writes K_{j+1} / V_j in its V_j (phase 2j), the younger half K_{j+2} / V_{j+1} in its V_j (phase
+    // 2j+1): every tile is complete a barrier before its first reader, and its stage (two per operand, as before) was last read two
+    // phases before its first writer.  Four-wave workgroups (two per CU: the key-chunk kernels) run the older half's sequence; their
+    // SIMD partners belong to another workgroup and drift into the complementary phase on their own (-6 .. -10 % against the
+    // interleaved form at 8192 / 16384 keys).  A grid that leaves ONE wave per SIMD has no partner to overlap with and keeps the
+    // interleaved form below (phases there: +17 % at one query of 2048 keys).
+    // Same MFMA order per accumulator in both forms: bit-identical results.
+    if constexpr (PHASES) {
+        constexpr bool TWO_HALVES = NWV == 2 * NW;
+        const bool upper = TWO_HALVES && wave >= NW;
+        Hi4 phi[2][2], plo[2][2];
+        // V_j on score tile st
+        auto stage = [&](int j, auto dly_t) __attribute__((always_inline)) {      // the staging part of V_j: the data were requested two phases ago
+            constexpr int dly = decltype(dly_t)::value;
+            const int tv = j + dly, tk = j + 1 + dly;
+            if (tv < nkt) lstore_v(tv & 1);
+            if (tk < nkt) lstore_k(tk & 1);
+            if (tv + 1 < nkt) gload_v(tv + 1);
+            if (tk + 1 < nkt) gload_k(tk + 1);
+        };
+        // P of one 16-key quarter as fp16 parts (phi, plo) and its share of the row sums
+        float ps4c[4], psumc, alphac;
+        auto convert = [&](int t, int u, f32x16 (&st)[2]) __attribute__((always_inline)) {
+            phi[t][u] = hi_parts(t, u, st, psumc);
+            if constexpr (PSPLIT) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
-            KFrag fa, fb;
-            VFrag va, vb;
-            kload(kbuf, 0, fa);
-            kload(kbuf, 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma(sn, 0, fa);
-            kload(kbuf, 2, fa);
-            kmma(sn, 1, fb);
-            kload(kbuf, 3, fb);
-            kmma(sn, 2, fa);
-            kmma(sn, 3, fb);
-            vload(vbuf, 0, 0, va);           // the first two quarters' V^T fragments travel under the end of phase A
-            vload(vbuf, 0, 1, vb);
-            const float alpha = softmax_a(sc);
-            // (the probabilities are only used behind the rescale branch: without a use in THIS block the compiler sinks the 32
-            // v_fma / v_exp pairs below it, out of the MFMAs' shadow)
-            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
-            // phase A: one score MFMA, then vector work of part A in its shadow: the row maximum first (everything else waits for
-            // it), then v_fma + v_exp pairs; the fragment reads go out with the first groups (K of the later k-steps, then V^T of
-            // the first quarters).  0x008 MFMA, 0x100 LDS read, 0x002 vector ALU, 0x400 transcendental.
-#pragma unroll
-            for (int g = 0; g < (HI ? 8 : 24); ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (g < (HI ? 8 : 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (g < (HI ? 2 : MAXG)) __builtin_amdgcn_sched_group_barrier(0x002, HI ? 16 : 4, 0);
-                else {
-                    __builtin_amdgcn_sched_group_barrier(0x002, HI ? 6 : 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, HI ? 6 : 2, 0);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float p0 = st[t][8 * u + 2 * jj], p1 = st[t][8 * u + 2 * jj + 1];
+                    // lo = fp16(p - hi) as ONE instruction per element: fma(p, 1, -hi) with the 1 hidden from the optimiser
+                    // selects v_fma_mixlo / mixhi_f16 (hi read as fp16 from its half of the packed register); a plain
+                    // p - (float)hi would be convert, subtract, convert.  Same value bit for bit (the difference is exact).
+                    const half2_t hk = phi[t][u].v[jj];
+                    plo[t][u].v[jj] = (half2_t){(_Float16)__builtin_fmaf(p0, one, -(float)hk[0]), (_Float16)__builtin_fmaf(p1, one, -(float)hk[1])};
+                    ps4c[jj] = (t == 0 && u == 0) ? p0 + p1 : ps4c[jj] + (p0 + p1);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto sums_done = [&]() __attribute__((always_inline)) {
+            if constexpr (PSPLIT) psumc = (ps4c[0] + ps4c[1]) + (ps4c[2] + ps4c[3]);
+            l_run = fmaf(l_run, alphac, psumc);
+        };
+        auto phase_v = [&](int j, f32x16 (&st)[2], auto last_t, auto dly_t) __attribute__((always_inline)) {
+            stage(j, dly_t);
+            if (decltype(last_t)::value && (klen & (BKV - 1)) && nkt == nkt_all) {      // last tile of the sequence: keys beyond klen
+                const int kbase = j * BKV;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + t * 32 + key_of(e, h) >= klen) st[t][e] = -INFINITY;
+            }
+#if AX_ABL == 1
+            alphac = 1.f; psumc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) asm volatile("" : "=v"(phi[q >> 1][q & 1].v[jj]), "=v"(plo[q >> 1][q & 1].v[jj]));
+            return;
+#endif
+#if AX_ABL == 4      // the vector work of the first tile only: real P in every product, no vector phase afterwards
+            if (j != t0) return;
+#endif
+            alphac = softmax_a(st);
+            rescale(alphac);
+            psumc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) convert(q >> 1, q & 1, st);
+            sums_done();
+        };
+        // one 16-key quarter of P V: the four products that take P_hi, then (PSPLIT) the two that take P_lo
+        auto vq = [&](int t, int u, const VFrag& f) __attribute__((always_inline)) {
+#if AX_ABL == 2
+            asm volatile("" :: "v"(f.h0), "v"(f.h1), "v"(f.l0), "v"(f.l1));
+            return;
+#endif
+            if constexpr (!HI) {
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, pack4(phi[t][u]), oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, pack4(phi[t][u]), oacc[1], 0, 0, 0);
+            }
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(phi[t][u]), oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(phi[t][u]), oacc[1], 0, 0, 0);
+            if constexpr (PSPLIT) {
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(plo[t][u]), oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(plo[t][u]), oacc[1], 0, 0, 0);
+            }
+        };
+        // X_j: O += V_j P_j (P_j from V_j) and, when a tile follows, S_{j+1} into sn; fragment reads one step ahead of their MFMAs
+        auto phase_x = [&](int j, f32x16 (&sn)[2], auto do_s_t) __attribute__((always_inline)) {
+            constexpr bool do_s = decltype(do_s_t)::value;
+            const int vbuf = j & 1, kbuf = (j + 1) & 1;
+            // two fragment slots in all (32 registers): each is refilled right behind the six MFMAs that consumed it, one group of six
+            // (~200 clocks) ahead of the group that needs it
+            VFrag va;
+            KFrag fa;
+            // the wave in its matrix phase goes first: its partner's vector work fills the gaps
+            if (AX_XPRIO) __builtin_amdgcn_s_setprio(1);
+            vload(vbuf, 0, 0, va);
+            if (do_s) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
+                kload(kbuf, 0, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(0, 0, va);
+                vload(vbuf, 0, 1, va);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(sn, 0, fa);
+                kload(kbuf, 1, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(0, 1, va);
+                vload(vbuf, 1, 0, va);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(sn, 1, fa);
+                kload(kbuf, 2, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(1, 0, va);
+                vload(vbuf, 1, 1, va);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(sn, 2, fa);
+                kload(kbuf, 3, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(1, 1, va);
+                kmma(sn, 3, fa);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                vq(0, 0, va);
+                vload(vbuf, 0, 1, va);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(0, 1, va);
+                vload(vbuf, 1, 0, va);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(1, 0, va);
+                vload(vbuf, 1, 1, va);
+                __builtin_amdgcn_sched_barrier(0);
+                vq(1, 1, va);
+            }
+            if (AX_XPRIO) __builtin_amdgcn_s_setprio(0);
+        };
+        // one tile: V_j, barrier, X_j, barrier (the younger half's very last X needs none: nobody waits for it)
+        auto tile = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto do_s_t, auto dly_t) __attribute__((always_inline)) {
+            PROF_STAMP(0);
+            phase_v(j, sc, std::integral_constant<bool, !decltype(do_s_t)::value>{}, dly_t);
             PROF_STAMP(1);
-            rescale(alpha);
+            __syncthreads();
+            PROF_STAMP(2);
+            phase_x(j, sn, do_s_t);
+            PROF_STAMP(3);
+            if (!(decltype(dly_t)::value == 1 && !decltype(do_s_t)::value)) __syncthreads();
+            PROF_STAMP(4);
+#ifdef PRAM_PROFILING
+            prof_ph[0] += prof_ts[1] - prof_ts[0]; prof_ph[1] += prof_ts[2] - prof_ts[1];
+            prof_ph[2] += prof_ts[3] - prof_ts[2]; prof_ph[3] += prof_ts[4] - prof_ts[3];
+#endif
+        };
+
+        // ---- prologue (tile numbers are absolute: t0 is even, the stage of a tile is its parity): K_{t0} staged by everybody; the
+        // younger half then spends its idle first phase putting its share of K_{t0+1} / V_{t0} into LDS and requesting K_{t0+2} / V_{t0+1};
+        // the older half requests K_{t0+1} / V_{t0} (written in its V_{t0}) and multiplies S_{t0}
+        gload_k(t0);
+        lstore_k(0);
+        __syncthreads();
+        f32x16 sa[2], sb[2];
+        if (upper) {
+            if (t0 + 1 < nkt) gload_k(t0 + 1);
+            gload_v(t0);
+            if (t0 + 1 < nkt) lstore_k(1);
+            lstore_v(0);
+            if (t0 + 2 < nkt) gload_k(t0 + 2);
+            if (t0 + 1 < nkt) gload_v(t0 + 1);
+            __syncthreads();
+        } else {
+            if (t0 + 1 < nkt) gload_k(t0 + 1);
+            gload_v(t0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sa[0][e] = 0.f; sa[1][e] = 0.f; }
+        if (wave_active) {      // "X_{t0 - 1}": only the scores of the first tile
+            KFrag fa, fb;
+            kload(0, 0, fa);
+            kload(0, 1, fb);
             __builtin_amdgcn_sched_barrier(0);
-            pv_b(vbuf, sc, alpha, va, vb);
-            // phase B as pv_b writes it: 4 v_cvt_pk in front, then per quarter 4 x { MFMA, v_fma_mixlo, v_fma_mixhi, v_add },
-            // { MFMA, the next quarter's 4 v_cvt_pk }, { MFMA, 4 v_add }; the two reloads of the fragment registers behind them
-            __builtin_amdgcn_sched_group_barrier(0x002, HI ? 8 : 4, 0);
+            kmma(sa, 0, fa);
+            kload(0, 2, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sa, 1, fb);
+            kload(0, 3, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sa, 2, fa);
+            kmma(sa, 3, fb);
+        }
+        __syncthreads();
+
+        // the two halves of an eight-wave workgroup run the same sequence with a different staging offset: instantiated per half, so that
+        // every LDS stage index is the tile's parity plus a constant
+        auto run = [&](auto dly_t) __attribute__((always_inline)) -> bool {
+            if (!wave_active) {
+                // a wave whose 32 query rows lie beyond the sequence: it still stages its share of every tile and meets every barrier
+                for (int j = t0; j < nkt; ++j) {
+                    stage(j, dly_t);
+                    __syncthreads();
+                    if (!(decltype(dly_t)::value == 1 && j == nkt - 1)) __syncthreads();
+                }
+                return false;
+            }
+            int j = t0;
+            const std::true_type more_t{};
+            const std::false_type last_t{};
+            if constexpr (MODE != 0) {
+                // Whole key chunks that are followed by at least one more tile: an even number of tiles (the score-tile ping-pong comes back
+                // to sa), then the chunk's end in straight-line code BETWEEN the tile loops — written as a branch inside the tile loop it
+                // made every accumulator a loop-carried phi of two definitions and cost ~100 register copies per tile.
+                while (nkt - j > CT) {
+        #pragma unroll 1
+                    for (int i = 0; i < CT; i += 2) {
+                        tile(j + i, sa, sb, more_t, dly_t);
+                        tile(j + i + 1, sb, sa, more_t, dly_t);
+                    }
+                    j += CT;
+                    chunk_end(j / CT - 1);
+                }
+            }
+            for (; j + 2 < nkt; j += 2) {
+                tile(j, sa, sb, more_t, dly_t);
+                tile(j + 1, sb, sa, more_t, dly_t);
+            }
+            if (j + 2 == nkt) {
+                tile(j, sa, sb, more_t, dly_t);
+                tile(j + 1, sb, sa, last_t, dly_t);
+            } else {
+                tile(j, sa, sb, last_t, dly_t);
+            }
+            return true;
+        };
+        const bool live = upper ? run(std::integral_constant<int, 1>{}) : run(std::integral_constant<int, 0>{});
+        if (!live) return;
+    } else {
+        // ---- The INTERLEAVED tile loop (round 5, first step): every wave runs S_{j+1} beside part A of the soft-max of tile j and
+        // O += V_j P_j beside part B, one barrier per tile.  It hides the vector work in the wave's OWN MFMA shadow, so it does not
+        // need a partner wave in the complementary phase: the form for grids that leave one wave per SIMD (a query or two).
+        // part B + P V of one tile, written in the order it is meant to issue (the sched_group_barriers behind the call pin it): per
+        // 16-key quarter the four products that take P_hi, each followed by one element pair's lo parts (v_fma_mixlo / mixhi) and its
+        // sum; then the two products that take P_lo, followed by the row-sum updates and the NEXT quarter's hi parts.
+        // va / vb: the V^T fragments of the first two quarters, already requested.
+        auto pv_b = [&](int vbuf, f32x16 (&st)[2], float alpha, VFrag& va, VFrag& vb) {
+            float ps4[4] = {0.f, 0.f, 0.f, 0.f}, psum = 0.f;
+            Hi4 hi = hi_parts(0, 0, st, psum);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                if constexpr (HI) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, PSPLIT ? 3 : 1, 0);
-                    }
+                const int t = qd >> 1, u = qd & 1;
+                VFrag& f = u ? vb : va;
+                Hi4 lo;
+                float pair[4];
+                auto lo_pair = [&](int j) __attribute__((always_inline)) {
                     if constexpr (PSPLIT) {
-                        if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        const float p0 = st[t][8 * u + 2 * j], p1 = st[t][8 * u + 2 * j + 1];
+                        // lo = fp16(p - hi) as ONE instruction per element: fma(p, 1, -hi) with the 1 hidden from the optimiser selects
+                        // v_fma_mixlo / mixhi_f16 (hi read as fp16 from its half of the packed register); a plain p - (float)hi would be
+                        // convert, subtract, convert.  Same value bit for bit (the difference is exact in fp32).
+                        const half2_t hk = hi.v[j];
+                        lo.v[j] = (half2_t){(_Float16)__builtin_fmaf(p0, one, -(float)hk[0]), (_Float16)__builtin_fmaf(p1, one, -(float)hk[1])};
+                        pair[j] = p0 + p1;
+                    }
+                };
+                if constexpr (!HI) {
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l0, pack4(hi), oacc[0], 0, 0, 0);
+                    lo_pair(0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.l1, pack4(hi), oacc[1], 0, 0, 0);
+                    lo_pair(1);
+                }
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(hi), oacc[0], 0, 0, 0);
+                lo_pair(2);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(hi), oacc[1], 0, 0, 0);
+                lo_pair(3);
+                Hi4 nhi = hi;
+                if (qd < 3) nhi = hi_parts((qd + 1) >> 1, (qd + 1) & 1, st, psum);
+                if constexpr (PSPLIT) {
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h0, pack4(lo), oacc[0], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ps4[j] += pair[j];
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.h1, pack4(lo), oacc[1], 0, 0, 0);
+                }
+                hi = nhi;
+                if (qd == 0) vload(vbuf, 1, 0, va);       // this quarter is through with va / vb: the fragments of quarter qd + 2
+                if (qd == 1) vload(vbuf, 1, 1, vb);
+            }
+            if constexpr (PSPLIT) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+            l_run = fmaf(l_run, alpha, psum);
+        };
+
+        // ---- prologue: K_0 | V_0, K_1 staged; S_0 multiplied on its own  (tile numbers relative to t0, which is even: the
+        // stage parity of a tile is that of its absolute number)
+        gload_k(t0);
+        lstore_k(0);
+        gload_v(t0);
+        if (t0 + 1 < nkt) gload_k(t0 + 1);
+        lstore_v(0);
+        if (t0 + 1 < nkt) lstore_k(1);
+        __syncthreads();
+        f32x16 sa[2], sb[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sa[0][e] = 0.f; sa[1][e] = 0.f; }
+        if (wave_active) {
+            KFrag fa, fb;
+            kload(0, 0, fa);
+            kload(0, 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sa, 0, fa);
+            kload(0, 2, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sa, 1, fb);
+            kload(0, 3, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma(sa, 2, fa);
+            kmma(sa, 3, fb);
+        }
+        // tile 0's K stage is rewritten (K_2) at the END of the first loop pass, before that pass's barrier: every wave must be done
+        // reading K_0 first
+        if (t0 + 2 < nkt) __syncthreads();
+
+        // tile j (not the last): S_{j+1} = K_{j+1} Q^T interleaved with softmax(S_j), then O += V_j P_j; K_{j+2} and V_{j+1} staged
+        auto mid = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+            const int kbuf = (j + 1) & 1, vbuf = j & 1;
+            const bool more_k = j + 2 < nkt;
+            PROF_STAMP(0);
+            gload_v(j + 1);
+            if (more_k) gload_k(j + 2);
+            if (wave_active) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sn[0][e] = 0.f; sn[1][e] = 0.f; }
+                KFrag fa, fb;
+                VFrag va, vb;
+                kload(kbuf, 0, fa);
+                kload(kbuf, 1, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma(sn, 0, fa);
+                kload(kbuf, 2, fa);
+                kmma(sn, 1, fb);
+                kload(kbuf, 3, fb);
+                kmma(sn, 2, fa);
+                kmma(sn, 3, fb);
+                vload(vbuf, 0, 0, va);           // the first two quarters' V^T fragments travel under the end of phase A
+                vload(vbuf, 0, 1, vb);
+                const float alpha = softmax_a(sc);
+                // (the probabilities are only used behind the rescale branch: without a use in THIS block the compiler sinks the 32
+                // v_fma / v_exp pairs below it, out of the MFMAs' shadow)
+                asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+                // phase A: one score MFMA, then vector work of part A in its shadow: the row maximum first (everything else waits for
+                // it), then v_fma + v_exp pairs; the fragment reads go out with the first groups (K of the later k-steps, then V^T of
+                // the first quarters).  0x008 MFMA, 0x100 LDS read, 0x002 vector ALU, 0x400 transcendental.
+#pragma unroll
+                for (int g = 0; g < (HI ? 8 : 24); ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (g < (HI ? 8 : 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (g < (HI ? 2 : SPREAD_MAXG)) __builtin_amdgcn_sched_group_barrier(0x002, HI ? 16 : 4, 0);
+                    else {
+                        __builtin_amdgcn_sched_group_barrier(0x002, HI ? 6 : 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x400, HI ? 6 : 2, 0);
                     }
                 }
-                if (qd < 2) __builtin_amdgcn_sched_group_barrier(0x100, HI ? 2 : 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                PROF_STAMP(1);
+                rescale(alpha);
+                __builtin_amdgcn_sched_barrier(0);
+                pv_b(vbuf, sc, alpha, va, vb);
+                // phase B as pv_b writes it: 4 v_cvt_pk in front, then per quarter 4 x { MFMA, v_fma_mixlo, v_fma_mixhi, v_add },
+                // { MFMA, the next quarter's 4 v_cvt_pk }, { MFMA, 4 v_add }; the two reloads of the fragment registers behind them
+                __builtin_amdgcn_sched_group_barrier(0x002, HI ? 8 : 4, 0);
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    if constexpr (HI) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, PSPLIT ? 3 : 1, 0);
+                        }
+                        if constexpr (PSPLIT) {
+                            if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                    }
+                    if (qd < 2) __builtin_amdgcn_sched_group_barrier(0x100, HI ? 2 : 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                PROF_STAMP(2);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            PROF_STAMP(2);
-        }
-        lstore_v((j + 1) & 1);
-        if (more_k) lstore_k(j & 1);
-        PROF_STAMP(3);
-        __syncthreads();
-        PROF_STAMP(4);
+            lstore_v((j + 1) & 1);
+            if (more_k) lstore_k(j & 1);
+            PROF_STAMP(3);
+            __syncthreads();
+            PROF_STAMP(4);
 #ifdef PRAM_PROFILING
-        prof_ph[0] += prof_ts[1] - prof_ts[0]; prof_ph[1] += prof_ts[2] - prof_ts[1];
-        prof_ph[2] += prof_ts[3] - prof_ts[2]; prof_ph[3] += prof_ts[4] - prof_ts[3];
+            prof_ph[0] += prof_ts[1] - prof_ts[0]; prof_ph[1] += prof_ts[2] - prof_ts[1];
+            prof_ph[2] += prof_ts[3] - prof_ts[2]; prof_ph[3] += prof_ts[4] - prof_ts[3];
 #endif
-    };
-    int j = t0;
-    if constexpr (MODE != 0) {
-        // Whole key chunks that are followed by at least one more tile: eight tiles (the score-tile ping-pong comes back to
-        // sa), then the chunk's end in straight-line code BETWEEN the tile loops — written as a branch inside the tile loop it
-        // made every accumulator a loop-carried phi of two definitions and cost ~100 register copies per tile (+13 % kernel
-        // time).  Its parking stores go out after the tile's staged loads were waited for; the next load wait is a tile away.
-        while (nkt - j > CT) {
+        };
+        int j = t0;
+        if constexpr (MODE != 0) {
+            // Whole key chunks that are followed by at least one more tile: eight tiles (the score-tile ping-pong comes back to
+            // sa), then the chunk's end in straight-line code BETWEEN the tile loops — written as a branch inside the tile loop it
+            // made every accumulator a loop-carried phi of two definitions and cost ~100 register copies per tile (+13 % kernel
+            // time).  Its parking stores go out after the tile's staged loads were waited for; the next load wait is a tile away.
+            while (nkt - j > CT) {
 #pragma unroll 1
-            for (int i = 0; i < CT; i += 2) {
-                mid(j + i, sa, sb);
-                mid(j + i + 1, sb, sa);
+                for (int i = 0; i < CT; i += 2) {
+                    mid(j + i, sa, sb);
+                    mid(j + i + 1, sb, sa);
+                }
+                j += CT;
+                if (wave_active) chunk_end(j / CT - 1);
             }
-            j += CT;
-            if (wave_active) chunk_end(j / CT - 1);
         }
-    }
-    for (; j + 2 < nkt; j += 2) {
-        mid(j, sa, sb);
-        mid(j + 1, sb, sa);
-    }
-    bool in_a = true;
-    if (j + 1 < nkt) { mid(j, sa, sb); in_a = false; ++j; }
-    if (!wave_active) return;
-    // last tile: mask the keys beyond klen, soft-max, P V
-    auto last = [&](f32x16 (&sc)[2]) {
-        if ((klen & (BKV - 1)) && nkt == nkt_all) {
-            const int kbase = (nkt - 1) * BKV;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (kbase + t * 32 + key_of(e, h) >= klen) sc[t][e] = -INFINITY;
+        for (; j + 2 < nkt; j += 2) {
+            mid(j, sa, sb);
+            mid(j + 1, sb, sa);
         }
-        VFrag va, vb;
-        vload((nkt - 1) & 1, 0, 0, va);
-        vload((nkt - 1) & 1, 0, 1, vb);
-        const float alpha = softmax_a(sc);
-        rescale(alpha);
-        __builtin_amdgcn_sched_barrier(0);
-        pv_b((nkt - 1) & 1, sc, alpha, va, vb);
-    };
-    if (in_a) last(sa); else last(sb);
+        bool in_a = true;
+        if (j + 1 < nkt) { mid(j, sa, sb); in_a = false; ++j; }
+        if (!wave_active) return;
+        // last tile: mask the keys beyond klen, soft-max, P V
+        auto last = [&](f32x16 (&sc)[2]) {
+            if ((klen & (BKV - 1)) && nkt == nkt_all) {
+                const int kbase = (nkt - 1) * BKV;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + t * 32 + key_of(e, h) >= klen) sc[t][e] = -INFINITY;
+            }
+            VFrag va, vb;
+            vload((nkt - 1) & 1, 0, 0, va);
+            vload((nkt - 1) & 1, 0, 1, vb);
+            const float alpha = softmax_a(sc);
+            rescale(alpha);
+            __builtin_amdgcn_sched_barrier(0);
+            pv_b((nkt - 1) & 1, sc, alpha, va, vb);
+        };
+        if (in_a) last(sa); else last(sb);
+    }
     finish();
 #ifdef PRAM_PROFILING
     if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
