@@ -44,7 +44,7 @@ constexpr float LAZY_T = 8.0f;          // lazy running maximum: it follows the 
 #define AX_STYLE8 1      // 256-row workgroups
 #endif
 #ifndef AX_STYLEC
-#define AX_STYLEC 1      // key chunks (fused and split)
+#define AX_STYLEC 1      // key chunks (fused and split): 1 = by the grid (phases from two workgroups per CU on), 2 = always phases, 0 = never
 #endif
 constexpr int SPREAD_MAXG = 7;          // interleaved form: leading MFMA groups of a tile's score phase that carry the row maximum
 #ifndef AX_ABL
@@ -150,7 +150,7 @@ static __device__ unsigned long long attn_prof[4096][4];
 static __device__ unsigned long long attn_phase[8][4];      // per wave of the workgroup: shader clocks per tile phase, summed over workgroups
 #endif
 
-constexpr bool style_phases(int mode, int nwv) { return mode != 0 ? AX_STYLEC : nwv == NW ? AX_STYLE4 : AX_STYLE8; }
+constexpr bool style_phases(int mode, int nwv) { return mode != 0 ? AX_STYLEC != 0 : nwv == NW ? AX_STYLE4 != 0 : AX_STYLE8 != 0; }
 
 template <bool PSPLIT, bool HI = false, int MODE = 0, int NWV = NW, bool PHASES = style_phases(MODE, NWV)>
 __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe_kernel(ArgsX p) {
@@ -1310,10 +1310,21 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
             return pram_launch_status("pram_attention_x3_f32");
         }
         const bool psplit = p_split_always();      // probabilities as two fp16 parts (three MFMAs per P V product) also from 1024 keys on
-#define PRAM_LAUNCH_PIPE(MODE_, GRID_)                                                                           \
-    do {                                                                                                         \
-        if (psplit) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, MODE_>), GRID_, blk, 0, st, p);    \
-        else hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, MODE_>), GRID_, blk, 0, st, p);          \
+        // the key-chunk kernels (128-row workgroups) run the phases form when the grid puts two workgroups on a CU — two waves on
+        // a SIMD — and a workgroup walks at least 2048 keys; the interleaved form otherwise (one frame split four ways: one wave
+        // per SIMD, nothing to overlap with; 512-key groups: the longer prologue of the phases form is not won back)
+#define PRAM_LAUNCH_PIPE_(MODE_, GRID_, PH_)                                                                                  \
+    do {                                                                                                                      \
+        if (psplit) hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, MODE_, NW, PH_>), GRID_, blk, 0, st, p);        \
+        else hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, MODE_, NW, PH_>), GRID_, blk, 0, st, p);              \
+    } while (0)
+#define PRAM_LAUNCH_PIPE(MODE_, GRID_, TILES_)                                                                                \
+    do {                                                                                                                      \
+        const dim3 g_ = GRID_;                                                                                                \
+        const bool ph_ = MODE_ != 0 ? (AX_STYLEC == 1 ? (long)g_.x * g_.y >= 2 * 256 && (TILES_) >= 32 : AX_STYLEC != 0)      \
+                                    : AX_STYLE4 != 0;                                                                         \
+        if (ph_) PRAM_LAUNCH_PIPE_(MODE_, g_, true);                                                                          \
+        else PRAM_LAUNCH_PIPE_(MODE_, g_, false);                                                                             \
     } while (0)
         const size_t need = x3_ws_bytes(batch, heads, m_max, n_max);
         static const char* force = getenv("PRAM_ATTN_MODE");      // profiling only: 0 = the unchunked kernel (different last bits), 1 = fused, 2 = split
@@ -1331,21 +1342,22 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
                 else hipLaunchKernelGGL((attention_x3_pipe_kernel<false, false, 0, 2 * NW>), grid8, blk8, 0, st, p);
                 return pram_launch_status("pram_attention_x3_f32");
             }
-            PRAM_LAUNCH_PIPE(0, grid);
+            PRAM_LAUNCH_PIPE(0, grid, 0);
             return pram_launch_status("pram_attention_x3_f32");
         }
         int groups = (workspace == nullptr || workspace_bytes < need || need == 0) ? 1 : x3_split_groups(batch, heads, m_max, n_max);
         if (fm == 2 && groups < 2 && workspace != nullptr && need != 0 && workspace_bytes >= need) groups = nchunks;
         if (groups < 2 || fm == 1 || fm == 3) {          // fused: the workgroup folds its chunks in registers (no workspace needed)
-            PRAM_LAUNCH_PIPE(1, grid);
+            PRAM_LAUNCH_PIPE(1, grid, cdiv(n_max, BKV));
             return pram_launch_status("pram_attention_x3_f32");
         }
         p.part_o = (float*)workspace;
         p.part_l = p.part_o + (size_t)nchunks * batch * m_max * heads * D;
         p.group_tiles = cdiv(nchunks, groups) * p.chunk_tiles;
         p.nsplit = cdiv(nchunks * p.chunk_tiles, p.group_tiles);
-        PRAM_LAUNCH_PIPE(2, dim3(grid.x, p.nsplit));
+        PRAM_LAUNCH_PIPE(2, dim3(grid.x, p.nsplit), p.group_tiles);
 #undef PRAM_LAUNCH_PIPE
+#undef PRAM_LAUNCH_PIPE_
         const long long rows = (long long)batch * m_max * heads;
         hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");

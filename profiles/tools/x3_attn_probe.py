@@ -22,6 +22,8 @@ def planes(t):
 SHAPES = ((16, 2048), (32, 2048), (8, 4096), (1, 2048), (2, 2048))
 if os.environ.get("PRAM_PROBE_SHAPES"):      # e.g. "4x2048,8x2048,12x2048": a batch sweep
     SHAPES = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["PRAM_PROBE_SHAPES"].split(","))
+if os.environ.get("PRAM_PROBE_SPLIT_TARGET"):      # workgroups a split launch aims at (bench.py --latency: 512)
+    ops._lib.load().pram_attention_x3_set_split_target(int(os.environ["PRAM_PROBE_SPLIT_TARGET"]))
 for B, N in SHAPES:
     q = torch.randn(B * N, 256, device=dev)
     k = torch.randn(B * N, 256, device=dev)
