@@ -115,7 +115,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
     const int tid = threadIdx.x;
     const int mlast = p.m - 1, nlast = p.n - 1;
     // all loads first (clamped addresses), then arithmetic, then predicated stores
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: tile bases live in scalar registers
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int cbase = col0 + wn * 64;
@@ -128,6 +128,13 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
     // sequences that are not part of this call — AdaGML commits the matching descriptors of the pairs stopping at a layer)
     const bool ragged = p.lens != nullptr;
     const bool full = (row0 + BM <= p.m) && (col0 + BN <= p.n) && !ragged;
+    // Full tiles (every row and column inside the matrix: all of them at the bench's shapes) address their loads and stores as a
+    // wave-uniform tile base (scalar registers) plus a 32-bit byte offset per lane — row e of a 32-row block is (e & 3) + 8 (e >> 2)
+    // leading dimensions further, a scalar product — instead of a 64-bit multiply-add per element and row (48 quarter-rate
+    // instructions per 32 stores before; the epilogue is vector-issue-bound, profiles/r05_gemm_epilogue.txt).
+    const unsigned unit_alpha = p.alpha == 1.0f;
+    float one = 1.0f;       // a 1.0 the optimiser cannot see through: fma(s, 1, -hi) stays an fma and selects v_fma_mixlo_f16
+    asm volatile("" : "+s"(one));
     float emax = 0.f;       // range guard: largest |value * out16_scale| this lane turned into split planes (valid rows only)
     // valid rows of a ragged tile: a tile inside one sequence (the rule: t_pad is a multiple of the tile height) has them up to a
     // row limit; a tile that straddles sequences asks row_valid per row
@@ -151,7 +158,16 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                 rs_[e] = p.rsin[rr];
             }
         }
-        if (p.residual) {
+        if (p.residual && full) {
+            const char* tile = reinterpret_cast<const char*>(p.residual + (size_t)(rbase + 32 * mi) * p.ldr + cbase);
+            const unsigned lane_off = ((unsigned)(4 * h) * (unsigned)p.ldr + r) * 4u, ld4 = (unsigned)p.ldr * 4u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned o = lane_off + (unsigned)((e & 3) + 8 * (e >> 2)) * ld4;
+                q0[e] = *reinterpret_cast<const float*>(tile + o);
+                q1[e] = *reinterpret_cast<const float*>(tile + o + 128);
+            }
+        } else if (p.residual) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const size_t rr = (size_t)min(rbase + acc_row(mi, e, h), mlast) * p.ldr;
@@ -159,10 +175,17 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                 q1[e] = p.residual[rr + c1c];
             }
         }
+        float a0_[16], a1_[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a0_[e] = acc[mi][0][e] + b0; a1_[e] = acc[mi][1][e] + b1; }
+        if (!unit_alpha) {      // (x * 1.0f is x: skipping the multiplication changes no bit)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a0_[e] *= p.alpha; a1_[e] *= p.alpha; }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            float v0 = (acc[mi][0][e] + b0) * p.alpha;
-            float v1 = (acc[mi][1][e] + b1) * p.alpha;
+            float v0 = a0_[e];
+            float v1 = a1_[e];
             if (rot) {
                 const float e0 = v0 * rc_[e] - v1 * rs_[e];   // even dim: t0*cos + (-t1)*sin
                 const float o0 = v1 * rc_[e] + v0 * rs_[e];   // odd dim : t1*cos + t0*sin
@@ -243,10 +266,12 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                         const bool ok = t0 + (i & 3) + 8 * (2 * g + (i >> 2)) + 4 * h < len;
                         const float s0 = ok ? q0[e] * p.out16_scale : 0.f, s1 = ok ? q1[e] * p.out16_scale : 0.f;
                         emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
-                        h0[i] = (_Float16)s0;
-                        l0[i] = (_Float16)(s0 - (float)h0[i]);
-                        h1[i] = (_Float16)s1;
-                        l1[i] = (_Float16)(s1 - (float)h1[i]);
+                        // lo = fp16(s - hi) as one v_fma_mix (the difference is exact: same bits as convert, subtract, convert)
+                        const _Float16 hh0 = (_Float16)s0, hh1 = (_Float16)s1;
+                        h0[i] = hh0;
+                        l0[i] = (_Float16)__builtin_fmaf(s0, one, -(float)hh0);
+                        h1[i] = hh1;
+                        l1[i] = (_Float16)__builtin_fmaf(s1, one, -(float)hh1);
                     }
                     const size_t d0 = (drow + r) * p.vt_tv + pos0 + 16 * g, d1 = (drow + 32 + r) * p.vt_tv + pos0 + 16 * g;
                     *reinterpret_cast<half8v*>(vh + d0) = h0;
@@ -266,31 +291,46 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
             constexpr int LD = 72;                                  // halves per staged row: 144 B, the two lane halves land 16 banks apart
             _Float16* sh = stage + wave * (2 * 32 * LD);
             _Float16* sl = sh + 32 * LD;
+            const bool block_full = full || (!straddle && rbase + mi * 32 + 32 <= rlimit);      // wave-uniform: all 32 rows count
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = acc_row(0, e, h);
                 const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
-                if (rvalid(rbase + mi * 32 + rr)) emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
+                if (block_full || rvalid(rbase + mi * 32 + rr)) emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
                 const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
                 sh[rr * LD + r] = h0;
                 sh[rr * LD + 32 + r] = h1;
-                sl[rr * LD + r] = (_Float16)(s0 - (float)h0);
-                sl[rr * LD + 32 + r] = (_Float16)(s1 - (float)h1);
+                sl[rr * LD + r] = (_Float16)__builtin_fmaf(s0, one, -(float)h0);
+                sl[rr * LD + 32 + r] = (_Float16)__builtin_fmaf(s1, one, -(float)h1);
             }
             _Float16* oh = reinterpret_cast<_Float16*>(p.out16);
             _Float16* ol = reinterpret_cast<_Float16*>(p.out16_lo);
             const int seg = lane & 7;
             const bool cok = cbase + seg * 8 < p.n;                 // n % 8 == 0 on this path
+            if (full) {
+                char* th = reinterpret_cast<char*>(oh + (size_t)(rbase + mi * 32) * p.ldo16 + cbase);
+                char* tl = reinterpret_cast<char*>(ol + (size_t)(rbase + mi * 32) * p.ldo16 + cbase);
+                const unsigned lane_off = ((unsigned)(lane >> 3) * (unsigned)p.ldo16 + seg * 8) * 2u, ld16 = (unsigned)p.ldo16 * 16u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rr = (lane >> 3) + 8 * j;
-                const int row = rbase + mi * 32 + rr;
-                const half8v vh = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
-                const half8v vl = *reinterpret_cast<const half8v*>(sl + rr * LD + seg * 8);
-                const bool ok = cok && rvalid(row);      // as the fp32 output below
-                if (ok) {
-                    *reinterpret_cast<half8v*>(oh + (size_t)row * p.ldo16 + cbase + seg * 8) = vh;
-                    *reinterpret_cast<half8v*>(ol + (size_t)row * p.ldo16 + cbase + seg * 8) = vl;
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = (lane >> 3) + 8 * j;
+                    const half8v vh = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
+                    const half8v vl = *reinterpret_cast<const half8v*>(sl + rr * LD + seg * 8);
+                    *reinterpret_cast<half8v*>(th + lane_off + j * ld16) = vh;
+                    *reinterpret_cast<half8v*>(tl + lane_off + j * ld16) = vl;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = (lane >> 3) + 8 * j;
+                    const int row = rbase + mi * 32 + rr;
+                    const half8v vh = *reinterpret_cast<const half8v*>(sh + rr * LD + seg * 8);
+                    const half8v vl = *reinterpret_cast<const half8v*>(sl + rr * LD + seg * 8);
+                    const bool ok = cok && rvalid(row);      // as the fp32 output below
+                    if (ok) {
+                        *reinterpret_cast<half8v*>(oh + (size_t)row * p.ldo16 + cbase + seg * 8) = vh;
+                        *reinterpret_cast<half8v*>(ol + (size_t)row * p.ldo16 + cbase + seg * 8) = vl;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // one 32-row block at a time: hoisting the next block's work up here spills
@@ -304,8 +344,8 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
                     const float s0 = q0[e] * p.out16_scale, s1 = q1[e] * p.out16_scale;
                     emax = fmaxf(fmaxf(emax, fabsf(s0)), fabsf(s1));
                     const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
-                    if (c0ok) { oh[(size_t)row * p.ldo16 + c0] = h0; ol[(size_t)row * p.ldo16 + c0] = (_Float16)(s0 - (float)h0); }
-                    if (c1ok) { oh[(size_t)row * p.ldo16 + c1] = h1; ol[(size_t)row * p.ldo16 + c1] = (_Float16)(s1 - (float)h1); }
+                    if (c0ok) { oh[(size_t)row * p.ldo16 + c0] = h0; ol[(size_t)row * p.ldo16 + c0] = (_Float16)__builtin_fmaf(s0, one, -(float)h0); }
+                    if (c1ok) { oh[(size_t)row * p.ldo16 + c1] = h1; ol[(size_t)row * p.ldo16 + c1] = (_Float16)__builtin_fmaf(s1, one, -(float)h1); }
                 }
             }
         } else if (p.out16 && stage) {
@@ -344,11 +384,13 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[
         }
         if (out == nullptr) continue;
         if (full) {   // block-uniform fast path: no per-element predicates
+            char* tile = reinterpret_cast<char*>(out + (size_t)(rbase + 32 * mi) * p.ldo + cbase);
+            const unsigned lane_off = ((unsigned)(4 * h) * (unsigned)p.ldo + r) * 4u, ld4 = (unsigned)p.ldo * 4u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float* o = out + (size_t)(rbase + acc_row(mi, e, h)) * p.ldo;
-                o[c0] = q0[e];
-                o[c1] = q1[e];
+                const unsigned o = lane_off + (unsigned)((e & 3) + 8 * (e >> 2)) * ld4;
+                *reinterpret_cast<float*>(tile + o) = q0[e];
+                *reinterpret_cast<float*>(tile + o + 128) = q1[e];
             }
         } else {
 #pragma unroll
