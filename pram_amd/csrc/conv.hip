@@ -186,7 +186,7 @@ __device__ __forceinline__ void conv_epilogue_planes(const ConvArgs& p, f32x16 (
                 if (p.residual) x += q[e];
                 if (relu) x = fmaxf(x, 0.f);
                 amax = fmaxf(amax, fabsf(x));
-                const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+                const _Float16 hi = (_Float16)x, lo = gemmx3::lo_part(x, hi);
                 const unsigned int mine = (unsigned int)__builtin_bit_cast(unsigned short, hi) | ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
                 const unsigned int other = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
                 const unsigned int pair = __builtin_amdgcn_perm(other, mine, sel);

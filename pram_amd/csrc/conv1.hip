@@ -184,8 +184,9 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
                         const int e = 4 * g4 + i;
                         const float x = fmaxf(fmaf(acc[e], ca[e], cc[e]), 0.f) * keep;      // 16 * ReLU(BN(conv + bias)), 0 outside the map
                         amax = fmaxf(amax, x);
-                        hi[g4][i] = (_Float16)x;
-                        lo[g4][i] = (_Float16)(x - (float)hi[g4][i]);
+                        const _Float16 hx = (_Float16)x;
+                        hi[g4][i] = hx;
+                        lo[g4][i] = gemmx3::lo_part(x, hx);
                     }
                 }
                 if (hpr < WP) {

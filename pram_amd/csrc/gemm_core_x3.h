@@ -51,13 +51,22 @@ struct alignas(16) Smem {
 
 __device__ __forceinline__ int swz(int slot, int row) { return slot ^ ((row >> 2) & 3); }
 
+// lo part of a split, fp16(x - hi), as ONE instruction: fma(x, 1, -hi) with the 1 hidden from the optimiser selects v_fma_mixlo /
+// mixhi_f16 (hi read as fp16); written as a subtraction it is convert, subtract, convert.  The difference is exact in fp32: same bits.
+__device__ __forceinline__ _Float16 lo_part(float x, _Float16 hi) {
+    float one = 1.0f;
+    asm("" : "+s"(one));
+    return (_Float16)__builtin_fmaf(x, one, -(float)hi);
+}
+
 // x * s -> (hi, lo) for four values
 __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo) {
     const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = (_Float16)x[i];
-        lo[i] = (_Float16)(x[i] - (float)hi[i]);
+        const _Float16 h = (_Float16)x[i];
+        hi[i] = h;
+        lo[i] = lo_part(x[i], h);
     }
 }
 
@@ -71,8 +80,9 @@ __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = (_Float16)x[i];
-        lo[i] = (_Float16)(x[i] - (float)hi[i]);
+        const _Float16 h = (_Float16)x[i];
+        hi[i] = h;
+        lo[i] = lo_part(x[i], h);
     }
 }
 
