@@ -548,6 +548,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
 #pragma unroll
             for (int q = 0; q < 4; ++q) convert(q >> 1, q & 1, st);
             sums_done();
+            // every lo part is computed HERE: left alone the compiler sinks half of the v_fma_mix into the head of the matrix phase (-0.5 .. -1 %)
+            if constexpr (PSPLIT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        half2_t& lo_ref = plo[q >> 1][q & 1].v[jj];
+                        asm volatile("" : "+v"(lo_ref));
+                    }
+            }
         };
         // one 16-key quarter of P V: the four products that take P_hi, then (PSPLIT) the two that take P_lo
         auto vq = [&](int t, int u, const VFrag& f) __attribute__((always_inline)) {
