@@ -309,6 +309,31 @@ def test_x3_attention_many_workgroups_every_mode(dev, chunk_keys, p_split):
         L.pram_attention_x3_set_p_split(prev)
 
 
+def test_x3_attention_tile_loop_forms_agree_bit_for_bit(dev):
+    """attention_x3_pipe_kernel has two forms of its tile loop (attention_x3.hip: vector / matrix PHASES across the two waves of a SIMD
+    for launches that fill the chip, the INTERLEAVED form for grids of one wave per SIMD) with the same MFMA order per accumulator:
+    16 sequences of 2048 keys in one launch (256-row workgroups, phases) give every sequence exactly the bits of its own launch
+    (128-row workgroups, interleaved), ragged lengths included; and both sit on the fp64 soft-max."""
+    S, T = 16, 2048
+    x = W.normal(31, "forms/x", (S * T, 256), 1.0).to(dev)
+    wq = W.normal(31, "forms/w", (768, 256), 0.06).to(dev)
+    lens = torch.tensor([T - 37 * (i % 5) for i in range(S)], dtype=torch.int32, device=dev)
+    pl, vt = ops.linear_qkv_planes(x, wq, None, 4, T, lens=lens)
+    q3, k3 = (pl[0][:, :256], pl[1][:, :256]), (pl[0][:, 256:512], pl[1][:, 256:512])
+    o_all = ops.attention_x3(q3, k3, vt, S, 4, T, T, 0.125, lens, lens)
+    _, plv = ops.linear(x, wq, None, split_out="only", lens=lens, t_pad=T)
+    full = (plv[0].double() + plv[1].double()) / 16
+    for s in range(0, S, 3):
+        n = int(lens[s])
+        sl = slice(s * T, (s + 1) * T)
+        o_one = ops.attention_x3((q3[0][sl], q3[1][sl]), (k3[0][sl], k3[1][sl]), tuple(v[s:s + 1].contiguous() for v in vt),
+                                 1, 4, T, T, 0.125, lens[s:s + 1], lens[s:s + 1])
+        assert torch.equal(o_all[s * T:s * T + n], o_one[:n]), s
+        qq, kk, vv = (full[s * T:s * T + n, c * 256:(c + 1) * 256].view(n, 4, 64).transpose(0, 1) for c in range(3))
+        want = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(n, 256)
+        assert float((o_all[s * T:s * T + n].double() - want).abs().max()) < 2e-6, s
+
+
 @pytest.mark.parametrize("ck", [512, 4096])
 def test_batched_matcher_equals_b1_with_split_attention(dev, chunk_keys, ck):
     """GML on 2048-keypoint sets: a batch of 5 pairs (fused attention launches) gives every pair exactly the bits of its own B = 1
