@@ -259,7 +259,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
             step(kt, g0, g1);
             if (kt + 1 < nk) step(kt + 1, g1, g0);
         }
-    } else if constexpr (ABL == 0 && SHADOW) {
+    } else if constexpr ((ABL == 0 || ABL >= 64) && SHADOW) {      // (64 / 128: whole-kernel ablations of the callers, the loop itself is the shipped one)
         // "Staging in the shadow" (round 5).  A SIMD runs its two waves almost one at a time (the older wave wins every issue
         // arbitration: profiles/r05_attn_phases.txt, r02_x3_gemm_phases.txt), so what a wave does outside its MFMA stream is paid
         // in full: the plain loop below spends ~700 clocks issuing a chunk's eight memory instructions in FRONT of its 48 MFMAs and

@@ -730,9 +730,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             __syncthreads();
             mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax, xf);
         } else {
-            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);
+            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, ABL == 128 ? 1 : (ABL == 256 && (blockIdx.x & 1) && blockIdx.x < 256) ? K / BK / 2 : K / BK, gemmx3::ACT_SCALE, acc, amax);
         }
         x3_range_flag(p.status, amax);
+    }
+    if constexpr (ABL == 64) {      // profiling: no epilogue (the accumulators kept alive by a store that never happens)
+        float sacc = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc += acc[mi][ni][e];
+        if (sacc == 1.2345e-30f) p.out[tid] = sacc;
+        return;
     }
     unsigned long long te0 = 0ull;
     if constexpr ((ABL & 4) != 0) te0 = __builtin_readcyclecounter();
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
     // the staging memory is idle now (the main loop ends on a barrier): the plane epilogue transposes through it
     _Float16* stage = (p.out16_lo && p.n % 8 == 0 && p.ldo16 % 8 == 0) ? reinterpret_cast<_Float16*>(smem_raw) : nullptr;
-    linear_epilogue<MI, WN>(p, acc, p.out, row0, col0, BM, BN, stage);
+    linear_epilogue<MI, WN>(p, acc, p.out, ABL == 512 ? 0 : row0, col0, BM, BN, stage);      // (512, profiling: every row tile stores to rows 0..255: the stores stay in the L2)
     if constexpr ((ABL & 4) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) atomicAdd(&gemmx3w::prof[6], (unsigned long long)__builtin_readcyclecounter() - te0);
@@ -893,6 +904,10 @@ void launch_linear_x3w_t(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _Fl
     else if (ab == 4) go(linear_x3w_kernel<MI, WM, WN, APLANES, 4>);      // phase clocks -> pram_debug_gemm_phases
     else if (ab == 16) go(linear_x3w_kernel<MI, WM, WN, APLANES, 16>);    // no A staging
     else if (ab == 32) go(linear_x3w_kernel<MI, WM, WN, APLANES, 32>);    // no B DMA
+    else if (ab == 64) go(linear_x3w_kernel<MI, WM, WN, APLANES, 64>);    // the shipped loop, no epilogue
+    else if (ab == 128) go(linear_x3w_kernel<MI, WM, WN, APLANES, 128>);  // ONE chunk of the shipped loop + the epilogue (fp32 A only)
+    else if (ab == 512) go(linear_x3w_kernel<MI, WM, WN, APLANES, 512>);  // every row tile stores to the first one's rows: the epilogue without its HBM writes
+    else if (ab == 256) go(linear_x3w_kernel<MI, WM, WN, APLANES, 256>);  // odd workgroups of the first round walk half their chunks: do de-synchronised CUs overlap store bursts with main loops?
     else go(linear_x3w_kernel<MI, WM, WN, APLANES, 3>);
 #else
     hipLaunchKernelGGL((linear_x3w_kernel<MI, WM, WN, APLANES>), dim3(p.tiles_m * p.tiles_n, batch), dim3(C::NT), shm, st, p, a, wh, wl, inv);
