@@ -1,5 +1,6 @@
 """x3 token GEMM at the step's shapes: time and a bit checksum of the output (variants that only move work must print the same sums).
     python profiles/tools/x3_gemm_quick.py"""
+import os
 import sys
 from pathlib import Path
 
@@ -16,6 +17,10 @@ for m, k0, k1, n in ((32768, 256, 0, 768), (32768, 256, 256, 512), (32768, 512, 
     x2 = torch.randn(m, k1, generator=g).to(dev) if k1 else None
     w = (torch.randn(n, k0 + k1, generator=g) / (k0 + k1) ** 0.5).to(dev)
     b = (torch.randn(n, generator=g) * 0.1).to(dev)
+    if os.environ.get("PRAM_PROBE_ZERO"):      # the same instruction stream on zero operands: what the power cap costs
+        x.zero_(); w.zero_(); b.zero_()
+        if x2 is not None:
+            x2.zero_()
     f = lambda: ops.linear(x, w, b, x2=x2, precision="x3")
     for _ in range(10):
         f()
