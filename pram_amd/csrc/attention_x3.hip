@@ -1316,7 +1316,16 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     hipStream_t st = (hipStream_t)stream;
     {
         if (n_max < 1024) {
-            hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0>), grid, blk, 0, st, p);
+            // short key sets (always two-part probabilities): 256-row workgroups in the phases form when they fill the chip — many small
+            // pairs in one grouped call (the matcher's real call pattern) — the 128-row interleaved kernel otherwise
+            static const char* wv4 = getenv("PRAM_ATTN_WAVES");
+            const long u256 = (long)batch * heads * cdiv(m_max, 2 * BQ);
+            if (u256 >= 256 && !(wv4 && wv4[0] == '4')) {
+                p.q_tiles = cdiv(m_max, 2 * BQ);
+                hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0, 2 * NW>), dim3(batch * heads * p.q_tiles), dim3(2 * NW * 64), 0, st, p);
+            } else {
+                hipLaunchKernelGGL((attention_x3_pipe_kernel<true, false, 0>), grid, blk, 0, st, p);
+            }
             return pram_launch_status("pram_attention_x3_f32");
         }
         const bool psplit = p_split_always();      // probabilities as two fp16 parts (three MFMAs per P V product) also from 1024 keys on
