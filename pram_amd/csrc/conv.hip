@@ -213,7 +213,7 @@ __global__ __launch_bounds__(gemm::NT, (gemm::Cfg<MI, WN, BKT>::WAVES)) void con
     const int pad = p.ks >> 1;
 
     // per-thread staging rows: decompose the output pixel once
-    int iy0[C::PA], ix0[C::PA];
+    int iy0[C::PA], ix0[C::PA], roff[C::PA];
     const float* base[C::PA];
     bool ok[C::PA];
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
     const int arow = tid >> 4, akq = tid & 15, brow = tid >> 3, bsl = tid & 7;
     const int row0 = tm * BM, col0 = tn * BN;
     const int pad = p.ks >> 1;
-    int iy0[C::PA], ix0[C::PA];
+    int iy0[C::PA], ix0[C::PA], roff[C::PA];
     const float* base[C::PA];
     bool ok[C::PA];
 #pragma unroll
@@ -299,21 +299,25 @@ __global__ __launch_bounds__(gemm16::NT, 2) void conv_f16_kernel(ConvArgs p, con
         iy0[pp] = oy * p.stride - pad;
         ix0[pp] = ox * p.stride - pad;
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
+        roff[pp] = (iy0[pp] * p.wd + ix0[pp]) * p.cin + akq * 4;      // as conv_x3_kernel: 32-bit element offsets inside an image
     }
     const int nlast = p.cout - 1;
     // taps innermost, like conv_x3_kernel below (L2 re-use of the input window); koff = the chunk's offset in a weight row
-    int cky = 0, ckx = 0, cci = 0, koff = 0;
+    int cky = 0, ckx = 0, cci = 0, koff = 0, tap = 0;
     auto adv = [&](int kt) {
-        if (kt == 0) { cky = ckx = cci = koff = 0; return; }
+        if (kt == 0) { cky = ckx = cci = koff = tap = 0; return; }
         if (++ckx == p.ks) { ckx = 0; if (++cky == p.ks) { cky = 0; cci += BK; } }
         koff = (cky * p.ks + ckx) * p.cin + cci;
+        tap = (cky * p.wd + ckx) * p.cin + cci;
     };
     const _Float16* brow16[C::PB];
 #pragma unroll
     for (int pp = 0; pp < C::PB; ++pp) brow16[pp] = w16 + (size_t)min(col0 + brow + 32 * pp, nlast) * p.k + bsl * 8;
     auto la = [&](int pp, int kt) -> float4 {
-        const int iyc = min(max(iy0[pp] + cky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
-        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + akq * 4);
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
+        const bool in = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+        const unsigned off = in ? (unsigned)(roff[pp] + tap) : 0u;      // a padding pixel reads the image's first elements: never used (oka)
+        return *reinterpret_cast<const float4*>(base[pp] + off);
     };
     auto oka = [&](int pp, int kt) -> bool {
         const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
     const int arow = tid >> 3, akq = tid & 7, brow = tid >> 2, bsl = tid & 3;
     const int row0 = tm * BM, col0 = tn * BN;
     const int pad = p.ks >> 1;
-    int iy0[C::PA], ix0[C::PA];
+    int iy0[C::PA], ix0[C::PA], roff[C::PA];
     const float* base[C::PA];
     bool ok[C::PA];
 #pragma unroll
@@ -357,6 +361,10 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
         iy0[pp] = oy * p.stride - pad;
         ix0[pp] = ox * p.stride - pad;
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
+        // the thread's element offset inside its image at tap (0, 0), chunk 0 (may be negative: the padding); a tap / chunk adds the
+        // workgroup-uniform `tap` — one v_add per load instead of clamps and a 64-bit multiply-add chain (an image holds < 2^31 elements:
+        // checked by the launcher)
+        roff[pp] = (iy0[pp] * p.wd + ix0[pp]) * p.cin + akq * 4;
     }
     const int nlast = p.cout - 1;
     // K is walked channel chunk by channel chunk with the ks x ks taps innermost: the nine shifted reads of a 32-channel slab
@@ -364,18 +372,21 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
     // outermost a workgroup came back to a line only after a whole tap (256 KB per workgroup, 8 MB per XCD against 4 MB of L2)
     // and the 3x3 layers fetched 3.4x their input from HBM (profiles/r02b_pmc_summary.md).  koff = the chunk's offset in the
     // [ky][kx][ci] rows of the weight matrix.
-    int cky = 0, ckx = 0, cci = 0, koff = 0;
+    int cky = 0, ckx = 0, cci = 0, koff = 0, tap = 0;
     auto adv = [&](int kt) {
-        if (kt == 0) { cky = ckx = cci = koff = 0; return; }
+        if (kt == 0) { cky = ckx = cci = koff = tap = 0; return; }
         if (++ckx == p.ks) { ckx = 0; if (++cky == p.ks) { cky = 0; cci += BK; } }
         koff = (cky * p.ks + ckx) * p.cin + cci;
+        tap = (cky * p.wd + ckx) * p.cin + cci;
     };
     size_t boff[C::PB];
 #pragma unroll
     for (int pp = 0; pp < C::PB; ++pp) boff[pp] = (size_t)min(col0 + brow + 64 * pp, nlast) * p.k + bsl * 8;
     auto la = [&](int pp, int kt) -> float4 {
-        const int iyc = min(max(iy0[pp] + cky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
-        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + akq * 4);
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
+        const bool in = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+        const unsigned off = in ? (unsigned)(roff[pp] + tap) : 0u;      // a padding pixel reads the image's first elements: never used (oka)
+        return *reinterpret_cast<const float4*>(base[pp] + off);
     };
     auto oka = [&](int pp, int kt) -> bool {
         const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
     const int arow = tid >> 3, akq = tid & 7, qrow = tid >> 2, qsl = tid & 3;
     const int row0 = tm * BM, col0 = tn * BN;
     const int pad = p.ks >> 1;
-    int iy0[C::PA], ix0[C::PA];
+    int iy0[C::PA], ix0[C::PA], roff[C::PA];
     const float* base[C::PA];
     bool ok[C::PA];
 #pragma unroll
@@ -430,6 +441,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
         iy0[pp] = oy * p.stride - pad;
         ix0[pp] = ox * p.stride - pad;
         base[pp] = p.in + (size_t)b * p.h * p.wd * p.cin;
+        // the thread's element offset inside its image at tap (0, 0), chunk 0 (may be negative: the padding); a tap / chunk adds the
+        // workgroup-uniform `tap` — one v_add per load instead of clamps and a 64-bit multiply-add chain (an image holds < 2^31 elements:
+        // checked by the launcher)
+        roff[pp] = (iy0[pp] * p.wd + ix0[pp]) * p.cin + akq * 4;
     }
     const int nlast = p.cout - 1;
     // K is walked channel chunk by channel chunk with the ks x ks taps innermost: the nine shifted reads of a 32-channel slab
@@ -437,18 +452,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
     // outermost a workgroup came back to a line only after a whole tap (256 KB per workgroup, 8 MB per XCD against 4 MB of L2)
     // and the 3x3 layers fetched 3.4x their input from HBM (profiles/r02b_pmc_summary.md).  koff = the chunk's offset in the
     // [ky][kx][ci] rows of the weight matrix.
-    int cky = 0, ckx = 0, cci = 0, koff = 0;
+    int cky = 0, ckx = 0, cci = 0, koff = 0, tap = 0;
     auto adv = [&](int kt) {
-        if (kt == 0) { cky = ckx = cci = koff = 0; return; }
+        if (kt == 0) { cky = ckx = cci = koff = tap = 0; return; }
         if (++ckx == p.ks) { ckx = 0; if (++cky == p.ks) { cky = 0; cci += BK; } }
         koff = (cky * p.ks + ckx) * p.cin + cci;
+        tap = (cky * p.wd + ckx) * p.cin + cci;
     };
     size_t boff[C::QB];
 #pragma unroll
     for (int pp = 0; pp < C::QB; ++pp) boff[pp] = (size_t)min(col0 + qrow + C::RQ * pp, nlast) * p.k + qsl * 8;
     auto la = [&](int pp, int kt) -> float4 {
-        const int iyc = min(max(iy0[pp] + cky, 0), p.h - 1), ixc = min(max(ix0[pp] + ckx, 0), p.wd - 1);
-        return *reinterpret_cast<const float4*>(base[pp] + ((size_t)iyc * p.wd + ixc) * p.cin + cci + akq * 4);
+        const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
+        const bool in = (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.wd;
+        const unsigned off = in ? (unsigned)(roff[pp] + tap) : 0u;      // a padding pixel reads the image's first elements: never used (oka)
+        return *reinterpret_cast<const float4*>(base[pp] + off);
     };
     auto oka = [&](int pp, int kt) -> bool {
         const int iy = iy0[pp] + cky, ix = ix0[pp] + ckx;
@@ -851,6 +869,7 @@ extern "C" int pram_conv2d_nhwc_f16_f32(const float* in, int batch, int h, int w
                                         float* out, int cout, int ks, int stride, int relu, void* stream) {
     PRAM_REQUIRE(in && wgt16 && out, "pram_conv2d_nhwc_f16_f32: null pointer");
     PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_f16_f32: ks must be 1 or 3");
+    PRAM_REQUIRE((long long)h * w * cin < (1ll << 31), "pram_conv2d_nhwc_f16_f32: an image of %d x %d x %d elements does not fit the 32-bit offsets of the im2col loader", h, w, cin);
     PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_f16_f32: stride must be 1 or 2");
     PRAM_REQUIRE(cin % 64 == 0, "pram_conv2d_nhwc_f16_f32: cin=%d must be a multiple of 64", cin);
     PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_f16_f32: scale and shift go together");
@@ -882,6 +901,7 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
                                        const float* residual, float* out, int cout, int ks, int stride, int relu, void* stream) {
     PRAM_REQUIRE(in && wgt_hi && wgt_lo && out, "pram_conv2d_nhwc_x3_f32: null pointer");
     PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_x3_f32: ks must be 1 or 3");
+    PRAM_REQUIRE((long long)h * w * cin < (1ll << 31), "pram_conv2d_nhwc_x3_f32: an image of %d x %d x %d elements does not fit the 32-bit offsets of the im2col loader", h, w, cin);
     PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_x3_f32: stride must be 1 or 2");
     PRAM_REQUIRE(cin % 32 == 0 && w_scale > 0.f, "pram_conv2d_nhwc_x3_f32: cin=%d must be a multiple of 32", cin);
     PRAM_REQUIRE((scale == nullptr) == (shift == nullptr), "pram_conv2d_nhwc_x3_f32: scale and shift go together");
@@ -955,6 +975,7 @@ extern "C" int pram_conv2d_nhwc_x3_l2norm_f32(const float* in, int batch, int h,
                                               const float* residual, float* out, int cout, int ks, int stride, int relu, void* stream) {
     PRAM_REQUIRE(in && wgt_hi && wgt_lo && out, "pram_conv2d_nhwc_x3_l2norm_f32: null pointer");
     PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_x3_l2norm_f32: ks must be 1 or 3");
+    PRAM_REQUIRE((long long)h * w * cin < (1ll << 31), "pram_conv2d_nhwc_x3_l2norm_f32: an image of %d x %d x %d elements does not fit the 32-bit offsets of the im2col loader", h, w, cin);
     PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_x3_l2norm_f32: stride must be 1 or 2");
     PRAM_REQUIRE(cin % 32 == 0 && w_scale > 0.f, "pram_conv2d_nhwc_x3_l2norm_f32: cin=%d must be a multiple of 32", cin);
     PRAM_REQUIRE(cout > 0 && cout <= 128, "pram_conv2d_nhwc_x3_l2norm_f32: cout=%d must be at most 128", cout);
@@ -983,6 +1004,7 @@ extern "C" int pram_conv2d_nhwc_x3_planes(const float* in, int batch, int h, int
                                           void* stream) {
     PRAM_REQUIRE(in && wgt_hi && wgt_lo && out_hi && out_lo, "pram_conv2d_nhwc_x3_planes: null pointer");
     PRAM_REQUIRE(ks == 1 || ks == 3, "pram_conv2d_nhwc_x3_planes: ks must be 1 or 3");
+    PRAM_REQUIRE((long long)h * w * cin < (1ll << 31), "pram_conv2d_nhwc_x3_planes: an image of %d x %d x %d elements does not fit the 32-bit offsets of the im2col loader", h, w, cin);
     PRAM_REQUIRE(stride == 1 || stride == 2, "pram_conv2d_nhwc_x3_planes: stride must be 1 or 2");
     PRAM_REQUIRE(cin % 32 == 0 && w_scale > 0.f, "pram_conv2d_nhwc_x3_planes: cin=%d must be a multiple of 32", cin);
     PRAM_REQUIRE(cout > 0 && cout % 2 == 0, "pram_conv2d_nhwc_x3_planes: cout=%d must be even", cout);
