@@ -48,7 +48,8 @@ constexpr float LAZY_T = 8.0f;          // lazy running maximum: it follows the 
 #endif
 constexpr int SPREAD_MAXG = 7;          // interleaved form: leading MFMA groups of a tile's score phase that carry the row maximum
 #ifndef AX_ABL
-#define AX_ABL 0      // profiling only (results are garbage): 1 no soft-max, 2 no MFMA, 3 no fragment reads, 4 soft-max of the first tile only
+#define AX_ABL 0      // profiling only (results are garbage): 1 no soft-max, 2 no MFMA, 3 no fragment reads, 4 soft-max of the first tile only,
+                      // 5 half of the K fragment reads (odd k-steps reuse the even ones' registers), 6 half of the K and V fragment reads
 #endif
 
 constexpr float P_EXP_SHIFT = 7.0f;     // probabilities carried as 2^7 p, at most 2^15 with the lazy maximum LAZY_T behind
@@ -265,6 +266,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
 
     struct KFrag { half8 h0, h1, l0, l1; };
     auto kload = [&](int buf, int c, KFrag& f) __attribute__((always_inline)) {
+#if AX_ABL == 5 || AX_ABL == 6      // odd k-steps reuse the fragments of the even ones: half of the K fragment reads, real operands
+        if (c & 1) return;
+#endif
 #if AX_ABL == 3
         asm volatile("" : "=v"(f.h0), "=v"(f.h1), "=v"(f.l0), "=v"(f.l1));
         return;
@@ -293,6 +297,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == NW ? 2 : 1) void attention_x3_pipe
     };
     struct VFrag { half8 h0, h1, l0, l1; };
     auto vload = [&](int buf, int t, int u, VFrag& f) __attribute__((always_inline)) {
+#if AX_ABL == 6      // half of the V fragment reads (and ABL 5's half of the K reads): what a 64-row wave would save
+        if (u & 1) return;
+#endif
 #if AX_ABL == 3
         asm volatile("" : "=v"(f.h0), "=v"(f.h1), "=v"(f.l0), "=v"(f.l1));
         return;
