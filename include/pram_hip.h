@@ -250,7 +250,7 @@ int pram_attention_x3_set_split_target(int workgroups);
 int pram_attention_x3_set_chunk_keys(int keys);
 int pram_attention_x3_mfma_per_tile(int n_max);
 /* probabilities in P V from 1024 keys on: 1 = two fp16 parts (three MFMAs per product; default), 0 = one fp16 (two MFMAs, ~15 % less
- * attention time, 2^-12 relative rounding per probability: logits 7e-4 instead of 4e-5 from the fp32 oracle on flat attention);
+ * attention time, 2^-12 relative rounding per probability: logits 7e-4..1.3e-3 instead of 4e-5 from the fp32 oracle on flat attention: outside the 1e-3 parity bar on some shapes, an opt-in that is NOT parity-gated);
  * also PRAM_ATTN_P=split|fp16 in the environment.  Negative = query; returns the value in force. */
 int pram_attention_x3_set_p_split(int split);
 int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq, const void* k_hi, const void* k_lo, int ldk,

@@ -28,6 +28,18 @@ static inline int pram_launch_status(const char* what) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Behaviour-changing environment switches (tile / kernel-form overrides) exist in profiling builds only (-DPRAM_PROFILING, e.g.
+// profiles/tools/build_variants.py TAG:file.hip:-DPRAM_PROFILING): the production library reads none of them.
+#include <stdlib.h>
+static inline const char* prof_env(const char* name) {
+#ifdef PRAM_PROFILING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // The caller-owned status word of the current device (pram_set_status_word), or nullptr.
 unsigned int* pram_status_ptr(void);
 // compute units of the current device (grid size of the persistent kernels)

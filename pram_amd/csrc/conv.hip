@@ -925,7 +925,7 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
         p.tiles_n = cdiv(cout, gemmx3::Cfg<MI_, WN_>::BN);                                                              \
         hipLaunchKernelGGL((conv_x3_kernel<MI_, WN_>), dim3(p.tiles_m * p.tiles_n), dim3(gemmx3::NT), 0, st, p, wh, wl, inv); \
     } while (0)
-    static const char* force = getenv("PRAM_X3_TILE");
+    static const char* force = prof_env("PRAM_X3_TILE");
     const char* halo_env = getenv("PRAM_CONV_HALO");      // "0": the per-tap staging kernel for every layer (profiling / the equality test; read per call)
     // PRAM_CONV_HALO: "0" = never, "w" = the 256-channel form only (what the 128-channel form buys is measured with it)
     if (ks == 3 && stride == 1 && (cout >= 256 || (cout == 128 && !(halo_env && halo_env[0] == 'w'))) && !(force && force[0] == 'n') &&

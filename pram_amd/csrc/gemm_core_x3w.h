@@ -80,20 +80,6 @@ __device__ __forceinline__ void dma_tile(_Float16* lds_hi, _Float16* lds_lo, Row
     }
 }
 
-// round i of dma_tile alone (wave w moves piece w + NWAVES i): for loops that issue a tile's DMA piecewise inside their MFMA stream
-template <int ROWS, int NWAVES, class RowPtr>
-__device__ __forceinline__ void dma_piece(_Float16* lds_hi, _Float16* lds_lo, RowPtr& rowptr, int i) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int PIECES = ROWS / 16;
-    const int piece = wave + NWAVES * i;
-    if (piece < 2 * PIECES) {
-        const int plane = piece / PIECES, pc = piece % PIECES;
-        const int row = pc * 16 + (lane >> 2);
-        const int slot = (lane & 3) ^ ((row >> 2) & 3);
-        __builtin_amdgcn_global_load_lds(rowptr(row, plane) + slot * 8, (plane ? lds_lo : lds_hi) + pc * 16 * BK, 16, 0, 0);
-    }
-}
-
 // APLANES = false: ALoad(p, kt) -> raw float4 A[row = tid/8 + RA p][kt*32 + (tid%8)*4 ..+3] (fp32, split here)
 // APLANES = true : ALoad(p, kt, plane) -> raw uint4 plane[row = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7]
 // BLoad(p, kt, plane) -> raw uint4 W_plane[col = tid/4 + RQ p][kt*32 + (tid%4)*8 ..+7];  *Ok: predicates;  Adv as gemm_core_x3.h
@@ -259,7 +245,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
             step(kt, g0, g1);
             if (kt + 1 < nk) step(kt + 1, g1, g0);
         }
-    } else if constexpr ((ABL == 0 || ABL >= 64) && SHADOW) {      // (64 / 128: whole-kernel ablations of the callers, the loop itself is the shipped one)
+    } else if constexpr ((ABL == 0 || ABL >= 64) && SHADOW && DMA >= 1) {      // (register-staged B, DMA == 0: the plain loop below)      // (64 / 128: whole-kernel ablations of the callers, the loop itself is the shipped one)
         // "Staging in the shadow" (round 5).  A SIMD runs its two waves almost one at a time (the older wave wins every issue
         // arbitration: profiles/r05_attn_phases.txt, r02_x3_gemm_phases.txt), so what a wave does outside its MFMA stream is paid
         // in full: the plain loop below spends ~700 clocks issuing a chunk's eight memory instructions in FRONT of its 48 MFMAs and
@@ -269,6 +255,8 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
         // 1 : 4 by sched_group_barrier — a VOP2 costs a wave 4 clocks, an MFMA 33.5, profiles/r05_mfma_valu_overlap.txt).  Same
         // MFMA order, same products: bit-identical to the plain loop.
         static_assert(MI == 4, "one staging piece per 32-row block of the 256-row tile");
+        // a tile's DMA leaves in MI rounds of one 1-KiB piece per wave: both planes of B (and of A when it travels that way) must fit
+        static_assert(2 * (C::BN / 16) <= (C::NT / 64) * MI && 2 * (C::BM / 16) <= (C::NT / 64) * MI, "MI DMA rounds cover the tile");
         Regs g;
         adv(0);
         issue(0, g);
@@ -335,7 +323,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
             }
         };
         // one k-step with a piece of staging work behind each 32-row block's six MFMAs
-        auto kstep_with = [&](int cur, int ks, auto&& piece, int vmem, int valu, int dsw) {
+        auto kstep_with = [&](int cur, int ks, auto&& piece) {
             const int arow0 = (wm * 32 * MI + r) * BK, brow0 = (wn * 64 + r) * BK;
             const int slot = swz(2 * ks + h, r) * 8;
             half8 bh[2], bl[2], ah[2], al[2];
@@ -360,7 +348,6 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi & 1], bh[ni], acc[mi][ni], 0, 0, 0);
                 piece(mi);
-                (void)vmem; (void)valu; (void)dsw;
             }
         };
         auto chunk = [&](int kt, auto more_t) {
@@ -378,7 +365,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
                         if (i == 2 || i == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
-            }, 0, 0, 0);
+            });
             kstep_with(kt & 1, 1, [&](int mi) {
                 if constexpr (more) {
                     commit_piece((kt + 1) & 1, mi);
@@ -389,7 +376,7 @@ __device__ __forceinline__ void mainloop(Smem<MI, WM, WN>& s, Adv& adv, ALoad& l
                         if (i == 5) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
                     }
                 }
-            }, 0, 0, 0);
+            });
             dma_wait();
             __syncthreads();
         };

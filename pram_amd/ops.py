@@ -1315,9 +1315,12 @@ def stage_frames(frames_u8: torch.Tensor, lut: torch.Tensor, out: Optional[torch
     _chk(frames_u8, "frames", torch.uint8)
     assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
     B, H, W, _ = frames_u8.shape
+    if not (lut.is_cuda and lut.device == frames_u8.device and lut.dtype == torch.float32 and lut.is_contiguous() and tuple(lut.shape) == (3, 256)):
+        raise _lib.PramHipError("stage_frames: lut must be the contiguous fp32 [3, 256] table of frame_lut() on the frames' device")
     if out is None:
         out = torch.empty(B, 3, H, W, device=frames_u8.device, dtype=torch.float32)
-    assert out.is_contiguous() and tuple(out.shape) == (B, 3, H, W) and out.dtype == torch.float32
+    if not (out.is_cuda and out.device == frames_u8.device and out.is_contiguous() and tuple(out.shape) == (B, 3, H, W) and out.dtype == torch.float32):
+        raise _lib.PramHipError("stage_frames: out must be a contiguous fp32 [B, 3, H, W] tensor on the frames' device")
     _lib.check(L.pram_stage_frames_u8(_p(frames_u8), _p(lut), _p(out), B, H, W, _st()), "pram_stage_frames_u8")
     return out
 

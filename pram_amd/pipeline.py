@@ -22,7 +22,14 @@ import torch
 from . import ops
 
 
-_BRANCH = {}      # (device index, main stream id) -> a stream that was MEASURED to run beside that main stream
+import threading as _threading
+
+# (device index, main stream handle) -> a stream that was MEASURED to run beside that main stream.  Process-wide and shared on
+# purpose: every pipeline / captured graph that forks beside the same main stream uses the SAME side stream (their branches are
+# ordered on it — graphs replayed on one main stream run one after the other anyway).  Guarded by _BRANCH_LOCK; entries live for
+# the process (a handle the runtime re-uses for a new stream keeps its measured partner: placement is for speed only).
+_BRANCH = {}
+_BRANCH_LOCK = _threading.Lock()
 
 
 def _branch_stream(device, main: Optional[torch.cuda.Stream] = None) -> torch.cuda.Stream:
@@ -33,13 +40,21 @@ def _branch_stream(device, main: Optional[torch.cuda.Stream] = None) -> torch.cu
     and nothing says so (measured: one-query latency 3.9 -> 5.1 ms = the serial sum, in a process that had created ~25 streams
     before; a high-priority stream made it 10.4; profiles/r05_stream_queue_collision.txt).  So the choice is measured, once per
     (device, main stream): two ~0.15 ms spin kernels (torch.cuda._sleep), one per stream; a candidate whose pair takes about the
-    time of one is kept.  Placement is for speed only; any stream gives the same results."""
+    time of one is kept.  Placement is for speed only; any stream gives the same results.
+
+    The measurement synchronises the device (~30 times) and must not run inside a stream capture: QueryPipeline.warm_up() /
+    GraphedPipeline's constructor do it ahead of time; a first forked run() that finds itself inside a capture raises instead of
+    invalidating it."""
     import time
     dev = torch.device(device)
     main = main or torch.cuda.current_stream(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
-    if key in _BRANCH:
-        return _BRANCH[key]
+    with _BRANCH_LOCK:
+        if key in _BRANCH:
+            return _BRANCH[key]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("pram_amd.pipeline: the side stream of a forked step has to be measured before a stream capture — call "
+                           "QueryPipeline.warm_up(device) (or run one step) outside the capture first")
 
     def spin(cands, cycles=300_000):
         torch.cuda.synchronize(dev)
@@ -61,8 +76,8 @@ def _branch_stream(device, main: Optional[torch.cuda.Stream] = None) -> torch.cu
             best, best_t = c, t
         if t < 1.5 * one:
             break
-    _BRANCH[key] = best
-    return best
+    with _BRANCH_LOCK:
+        return _BRANCH.setdefault(key, best)      # (another thread may have measured the same pair meanwhile: one winner)
 
 
 class QueryPipeline:
@@ -82,6 +97,14 @@ class QueryPipeline:
         self.guard = guard
         self.match_keypoints = int(match_keypoints)
         self._side, self._side_main = None, None
+
+    def warm_up(self, device, main: Optional[torch.cuda.Stream] = None) -> None:
+        """Measure the side stream of forked steps (batches below overlap_below) beside ``main`` (default: the current stream) NOW:
+        ~30 device synchronisations that would otherwise happen inside the first forked run() — and must not happen inside a
+        stream capture or beside another thread's timing."""
+        dev = torch.device(device)
+        main = main or torch.cuda.current_stream(dev)
+        self._side, self._side_main = _branch_stream(dev, main), main.cuda_stream
 
     def _match(self, ex, ref, W, H):
         kpts, scores, counts, desc = ex['keypoints'], ex['scores'], ex['counts'], ex['descriptors']
@@ -288,7 +311,8 @@ class GraphedPipeline:
             self.g_f.replay()
 
     def _run_eager(self):
-        # the forked branch runs on a side stream owned by THIS graph (the pipeline's own side stream keeps serving eager runs)
+        # the forked branch runs on the side stream measured for the stream this graph replays on (_branch_stream: shared with
+        # whatever else forks beside that stream — their branches are ordered on it); the pipeline's own choice is put back after
         dev = self.images.device
         saved = (self.pipe._side, self.pipe._side_main)
         self.pipe._side, self.pipe._side_main = self._side, torch.cuda.current_stream(dev).cuda_stream

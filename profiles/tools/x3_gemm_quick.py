@@ -35,3 +35,28 @@ for m, k0, k1, n in ((32768, 256, 0, 768), (32768, 256, 256, 512), (32768, 512, 
     cs = int(y.view(torch.int32).to(torch.int64).sum().item())
     out.append(f"{m}x{k0}+{k1}x{n}: {us:.1f} us {2.0 * m * (k0 + k1) * n / us / 1e6:.0f} TF #{cs & 0xffffff:06x}")
 print(" | ".join(out))
+# round 6: the two GEMMs of an MLP tail at the step's shapes (first: fp32 out + row statistics; second: LayerNorm + GELU staging, + residual),
+# and a plain fp32 GEMM with a residual
+out = []
+for m in (32768, 65536):
+    x = torch.randn(m, 256, generator=g).to(dev)
+    c = torch.randn(m, 256, generator=g).to(dev)
+    w0, b0 = (t.to(dev) for t in ops.center_linear((torch.randn(512, 512, generator=g) / 512 ** 0.5).to(dev), (torch.randn(512, generator=g) * 0.1).to(dev)))
+    gam, bet = (1 + 0.1 * torch.randn(512, generator=g)).to(dev), (0.1 * torch.randn(512, generator=g)).to(dev)
+    w3, b3 = (torch.randn(256, 512, generator=g) / 512 ** 0.5).to(dev), (torch.randn(256, generator=g) * 0.1).to(dev)
+    w3a = w3[:, :256].contiguous()
+    fs = {"tail": lambda: ops.mlp_tail(x, w0, b0, gam, bet, w3, b3, x2=c, residual=x),
+          "res": lambda: ops.linear(x, w3a, b3, residual=x, precision="x3")}
+    for name, f in fs.items():
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            y = f()
+        e1.record()
+        torch.cuda.synchronize()
+        cs = int(y.view(torch.int32).to(torch.int64).sum().item())
+        out.append(f"{name} {m}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us #{cs & 0xffffff:06x}")
+print(" | ".join(out))
