@@ -486,7 +486,7 @@ class Job:
     hipGraph per lane) and the step function."""
 
     def __init__(self, dev, rank, world, q0, B, matcher_name, kpts, n_class, stages, inflight, use_graph, precision=None,
-                 ref_kpts=0, match_kpts=0, shard_sizes=None, segk=0, h2d=False, rotate=1):
+                 ref_kpts=0, match_kpts=0, shard_sizes=None, segk=0, h2d=False, rotate=1, act_scale=None):
         from pram_amd import ops, weights as Wt
         from pram_amd.pipeline import GraphedPipeline, QueryPipeline
         self.dev, self.world, self.B, self.stages, self.matcher_name = dev, world, B, stages, matcher_name
@@ -495,6 +495,8 @@ class Job:
         self.sfd2, self.seg, self.matcher, self.sds = build_models(dev, matcher_name, n_class)
         for m in (self.sfd2, self.seg, self.matcher):
             m.set_precision(precision)
+            if act_scale is not None:      # the split planes carry value * act_scale instead of value * 16 (what the range guard would settle on for a hot checkpoint)
+                m.set_act_scale(act_scale)
         # the bench keeps several steps in flight: the range guard is read once, after the timed region (guard="deferred")
         self.pipe = QueryPipeline(self.sfd2, self.seg, self.matcher, max_keypoints=kpts, min_keypoints=128, guard="deferred",
                                   match_keypoints=match_kpts)
@@ -992,6 +994,9 @@ def main():
                 warm_=6, sustain_s=10.0, rotate=4)
         alt_run("adagml", "same step with the AdaGML matcher (BASELINE configs[2] names it; pruning / early exit are data-dependent)", matcher_name="adagml",
                 parity_q=4)
+        alt_run("act_scale_1", "same step with every model's activation planes at scale 1 instead of 16 (|x| < 65520 instead of 4094.97): where the range "
+                "guard leaves a checkpoint with hot activations — the split kernels at the same speed, not the exact-fp32 kernels (alt.exact_f32 is "
+                "what a tripped guard cost before round 6)", act_scale=1.0, parity_q=4)
         alt_run("exact_f32", "same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)", precision="f32")
         alt_run("gml_512x1024", "secondary matcher shape of SURVEY 8(d): the 512 best keypoints of a query against 1024-keypoint reference sets",
                 ref_kpts=1024, match_kpts=512)

@@ -24,7 +24,8 @@
  *     (pram_select_keypoints_workspace_bytes accounts for it) and max_keypoints >= h * w keeps everything unsorted;
  *   - AdaGML pruning handles token sets of at most 8192 tokens (pram_adagml_prune_f32);
  *   - LayerNorm rows are at most 1024 wide; the split-fp16 GEMMs need K % 32 == 0 (other shapes: the exact-fp32 entry);
- *   - the split-fp16 operands carry value * 16 in fp16: a finite |x| >= 4094.97 does not fit.  This one is NOT a silent limit
+ *   - the split-fp16 operands carry value * s in fp16 (s = 16 by default, pram_x3_set_act_scale): a finite |x| >= 65520 / s
+ *     (4094.97) does not fit.  This one is NOT a silent limit
  *     either: see "range guard" below (pram_set_status_word) — the kernels report it, and pram_amd's Python layer re-runs the
  *     call on the exact-fp32 entries (or raises).
  */
@@ -58,6 +59,15 @@ const char* pram_last_error(void);
  *                          the word if it was set.  A caller that sees PRAM_STATUS_X3_RANGE re-runs on the *_f32 entries. */
 #define PRAM_STATUS_X3_RANGE 1u
 int pram_set_status_word(unsigned int* device_word);
+/* Activation scale.  The planes carry value * s with s = 16 by default: the range is |x| < 65520 / s = 4094.97 and values down
+ * to 2^-25 / s keep their last bit (the lo part is an fp16 subnormal below 2^-14).  A model whose activations are larger (trained
+ * checkpoints; the range guard trips) lowers s instead of leaving the split path: s = 1 carries |x| < 65520 with an absolute floor
+ * of 3e-8, s = 2^-4 a million with 4.8e-7 — the pair (hi, lo) is a 22-bit significand whatever the scale, only the floor moves.
+ *   pram_x3_set_act_scale(s): s = a power of two in [2^-12, 2^4] -> sets the scale for the CALLING HOST THREAD and returns the
+ *   previous one; s <= 0 only queries; anything else returns -1 and changes nothing.  Every x3 entry reads it at launch and
+ *   hands it to its kernel by value: planes written under one setting must be consumed under the same setting (pram_amd's models
+ *   set it around their forward, nets/_blocks.py); a captured hipGraph replays with the value it was captured under. */
+float pram_x3_set_act_scale(float scale);
 int pram_read_status_word(unsigned int* host_out, int reset, void* stream);
 
 /* ---------------------------------------------------------------- token linear algebra */

@@ -23,6 +23,7 @@ _SIGS = {
     "pram_last_error": (C.c_char_p, []),
     "pram_set_status_word": (I, [P]),
     "pram_read_status_word": (I, [P, I, P]),
+    "pram_x3_set_act_scale": (F, [F]),
     "pram_linear_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_f16_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P]),
     "pram_linear_f16_ragged_f32": (I, [P, I, I, P, I, I, P, P, P, I, P, I, I, I, F, I, P, P, I, P, I, P]),

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = fast_exp2(fmaf(st[t][e], p.scale2, -m_new));
+                    // the ROUNDED product, like the row maximum above (m_new >= tmax * scale2, rounded): the argument is <= 0 whatever
+                    // the scores' magnitude.  (An fma subtracts m_new from the exact product; at |score| ~ 1e9 — a hot residual stream on
+                    // the range guard's last resort — the product's rounding error alone is up to +128 and exp2 of it is inf.)
+                    const float pv = fast_exp2(st[t][e] * p.scale2 - m_new);
                     st[t][e] = pv;
                     psum += pv;
                 }

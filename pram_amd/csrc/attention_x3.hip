@@ -30,7 +30,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int D = 64, QW = 32, NW = 4, BQ = QW * NW, BKV = 64;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float IN_SCALE = 16.0f;       // scale of the q / k / v planes (gemmx3::ACT_SCALE)
+// (the q / k / v planes carry value * pram_act_scale(), 16 by default: ArgsX::in_scale / scale2 get it at launch)
 constexpr float LAZY_T = 8.0f;          // lazy running maximum: it follows the row maximum only when left behind by more than 2^8
 #ifndef AX_XPRIO
 #define AX_XPRIO 1
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == NW && MODE != 1) ? 2 : 1) void at
     // end of a key chunk inside the walk (MODE 1 / 2): normalise it, fold it (1) or park it (2), start afresh
     auto chunk_end = [&](int c) __attribute__((always_inline)) {
         const float l_c = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;      // undoes the 2^P_EXP_SHIFT of P (carried by l_c) and the scale of V
+        const float inv = (1.0f / p.in_scale) / l_c;      // undoes the 2^P_EXP_SHIFT of P (carried by l_c) and the scale of V
         const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
         if constexpr (MODE == 2) {
             if (q_ok) {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == NW && MODE != 1) ? 2 : 1) void at
     // after the last tile: the last chunk normalised in place (oacc), l_tot2 = its log2-sum-exp; MODE 1 then folds it into the total
     auto finish = [&]() __attribute__((always_inline)) {
         const float l_c = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = (1.0f / (HI ? p.in_scale : IN_SCALE)) / l_c;
+        const float inv = (1.0f / p.in_scale) / l_c;
         const float lse_c = m_run + (log2f(l_c) - P_EXP_SHIFT);
 #pragma unroll
         for (int e = 0; e < 16; ++e) { oacc[0][e] *= inv; oacc[1][e] *= inv; }
@@ -1195,7 +1195,7 @@ extern "C" int pram_attention_x3_colmean_f32(const void* q_hi, const void* q_lo,
     PRAM_REQUIRE(batch >= 0 && heads > 0 && m_max >= 0 && n_max >= 0 && kv_shift >= 0, "pram_attention_x3_colmean_f32: bad sizes");
     if (batch == 0 || n_max == 0) return PRAM_OK;
     ColArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, lse2, colmean, q_lens, k_lens,
-               ldq, ldk, batch, heads, m_max, n_max, scale * LOG2E / (IN_SCALE * IN_SCALE), kv_shift};
+               ldq, ldk, batch, heads, m_max, n_max, scale * LOG2E / (pram_act_scale() * pram_act_scale()), kv_shift};
     hipLaunchKernelGGL(colmean_x3_kernel, dim3(cdiv(n_max, 128), batch), dim3(256), 0, (hipStream_t)stream, p);
     return pram_launch_status("pram_attention_x3_colmean_f32");
 }
@@ -1322,7 +1322,7 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
     PRAM_REQUIRE((long long)n_max * ldk * 2 < (1ll << 32) && 64ll * (cdiv(n_max, 64) * 64) * 2 < (1ll << 32), "pram_attention_x3_f32: a sequence's K rows / V^T planes must span < 4 GiB");
     ArgsX p{(const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)k_hi, (const _Float16*)k_lo, (const _Float16*)vt_hi,
             (const _Float16*)vt_lo, out, lse2, q_lens, k_lens, ldq, ldk, cdiv(n_max, 64) * 64, ldo, batch, heads, m_max, n_max,
-            scale * LOG2E / (IN_SCALE * IN_SCALE), cdiv(m_max, BQ), kv_shift, IN_SCALE, 1, 0, chunk_tiles(), nullptr, nullptr};
+            scale * LOG2E / (pram_act_scale() * pram_act_scale()), cdiv(m_max, BQ), kv_shift, pram_act_scale(), 1, 0, chunk_tiles(), nullptr, nullptr};
     const dim3 grid(batch * heads * p.q_tiles), blk(256);
     hipStream_t st = (hipStream_t)stream;
     {

@@ -1,5 +1,6 @@
 // Error channel and version of libpram_hip.so.
 #include <stdarg.h>
+#include <math.h>
 #include <stdio.h>
 #include "common.h"
 
@@ -33,6 +34,22 @@ int pram_cu_count(void) {
         g_cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
     return g_cus[dev];
+}
+
+// ---- scale of the split-fp16 activation planes (include/pram_hip.h, "activation scale"): per host thread
+static thread_local float g_act_scale = 16.0f;
+
+float pram_act_scale(void) { return g_act_scale; }
+
+extern "C" float pram_x3_set_act_scale(float scale) {
+    const float prev = g_act_scale;
+    if (scale > 0.f) {
+        int e = 0;
+        const float m = frexpf(scale, &e);      // a power of two in [2^-12, 2^4]: scaling stays exact, the planes stay inside fp16
+        if (m == 0.5f && e - 1 >= -12 && e - 1 <= 4) g_act_scale = scale;
+        else return -1.0f;
+    }
+    return prev;
 }
 
 extern "C" int pram_set_status_word(unsigned int* device_word) {

@@ -44,6 +44,10 @@ static inline const char* prof_env(const char* name) {
 unsigned int* pram_status_ptr(void);
 // compute units of the current device (grid size of the persistent kernels)
 int pram_cu_count(void);
+// Scale of the split-fp16 ACTIVATION planes in force for the calling host thread (pram_x3_set_act_scale; default 16 =
+// gemmx3::ACT_SCALE): every kernel that writes or reads activation planes gets it by value at launch, so producers and consumers
+// launched under one setting agree, and a captured graph keeps the value it was captured with.
+float pram_act_scale(void);
 
 // Range guard of the split-fp16 path: a kernel that turns fp32 values into fp16(value * scale) parts tracks the largest
 // |value * scale| it met; 65520 and above round to +-inf in fp16 (a finite result would be garbage, usually NaN), which is

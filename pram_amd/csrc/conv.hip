@@ -22,7 +22,8 @@ struct ConvArgs {
     int ho, wo, m, k;
     int tiles_m, tiles_n;
     unsigned int* status;      // range guard of the split-fp16 path (common.h), or nullptr
-    _Float16* out_hi; _Float16* out_lo;      // PLANES epilogue: the output * 16 as two fp16 planes (the next layer's split operand)
+    _Float16* out_hi; _Float16* out_lo;      // PLANES epilogue: the output * act_scale as two fp16 planes (the next layer's split operand)
+    float act_scale = gemmx3::ACT_SCALE;     // split-fp16 path: scale of the activation planes (pram_act_scale() at launch)
 };
 
 // Shared epilogue of the fp32 and fp16 main loops: bias -> BN scale/shift -> residual -> ReLU.
@@ -168,8 +169,8 @@ __device__ __forceinline__ void conv_epilogue_planes(const ConvArgs& p, f32x16 (
         const int col = col0 + wn * 64 + ni * 32 + r;
         const int cc = min(col, nlast);
         const float bi = p.bias ? p.bias[cc] : 0.f;
-        const float sc = (p.scale ? p.scale[cc] : 1.f) * gemmx3::ACT_SCALE;
-        const float sh = (p.scale ? p.shift[cc] : 0.f) * gemmx3::ACT_SCALE;
+        const float sc = (p.scale ? p.scale[cc] : 1.f) * p.act_scale;
+        const float sh = (p.scale ? p.shift[cc] : 0.f) * p.act_scale;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int rb = rbase + 32 * mi + 4 * h;
@@ -177,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue_planes(const ConvArgs& p, f32x16 (
             if (p.residual) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    q[e] = p.residual[(size_t)min(rb + (e & 3) + 8 * (e >> 2), mlast) * p.cout + cc] * gemmx3::ACT_SCALE;
+                    q[e] = p.residual[(size_t)min(rb + (e & 3) + 8 * (e >> 2), mlast) * p.cout + cc] * p.act_scale;
             }
             unsigned int* dst = plane + (size_t)rb * hc + ((unsigned int)(col & ~1) >> 1);
 #pragma unroll
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void conv_x3_kernel(ConvArgs p, cons
     auto okb = [&](int pp, int kt) -> bool { return (col0 + brow + 64 * pp) < p.cout; };
     f32x16 acc[MI][2];
     float amax = 0.f;
-    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, ACT_SCALE, acc, amax);
+    mainloop<MI, WN>(smem, adv, la, oka, lb, okb, p.k / BK, p.act_scale, acc, amax);
     x3_range_flag(p.status, amax);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_x3w_kernel(ConvArgs p, c
         return (plane ? wl : wh) + (size_t)min(col0 + row, nlast) * p.k + koff;
     };
     float amax = 0.f;
-    mainloop<MI, WM, WN, false, 0, 1>(smem, adv, la, oka, lb, okb, aptr, bptr, p.k / BK, gemmx3::ACT_SCALE, acc, amax);
+    mainloop<MI, WM, WN, false, 0, 1>(smem, adv, la, oka, lb, okb, aptr, bptr, p.k / BK, p.act_scale, acc, amax);
     x3_range_flag(p.status, amax);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(halo::NT, 1) void conv3x3_x3h_kernel(ConvArgs p, co
             float4 v = hv[j];
             if (!g.inimg) v = make_float4(0.f, 0.f, 0.f, 0.f);
             half4 hi, lo;
-            gemmx3::split4(v, gemmx3::ACT_SCALE, hi, lo, amax);
+            gemmx3::split4(v, p.act_scale, hi, lo, amax);
             if (g.valid) {
                 const int off = g.hp * BK + gemmx3::swz(g.q >> 1, g.hp) * 8 + (g.q & 1) * 4;
                 *reinterpret_cast<half4*>(&s.ah[buf][off]) = hi;
@@ -653,6 +654,8 @@ __global__ __launch_bounds__(halo::NT, 1) void conv3x3_x3h_kernel(ConvArgs p, co
     x3_range_flag(p.status, amax);
     // epilogue: tile row tr = 32 y + x  ->  output pixel (b, oy0 + y, ox0 + x); bias -> BN scale / shift -> residual -> ReLU
     const int rbase = wm * 32 * MI;
+    float* out_b = p.out + (size_t)b * p.ho * p.wo * p.cout;
+    const float* res_b = p.residual ? p.residual + (size_t)b * p.ho * p.wo * p.cout : nullptr;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = col0 + wn * 64 + ni * 32 + r;
@@ -667,12 +670,13 @@ __global__ __launch_bounds__(halo::NT, 1) void conv3x3_x3h_kernel(ConvArgs p, co
                 const int tr = rbase + gemm::acc_row(mi, e, h);
                 const int oy = oy0 + (tr >> 5), ox = ox0 + (tr & 31);
                 if (oy < p.ho && ox < p.wo && col < p.cout) {
-                    const size_t o = (((size_t)b * p.ho + oy) * p.wo + ox) * p.cout + col;
+                    // a batch element's map holds < 2^31 floats (checked by the entry point): 32-bit offsets from its (scalar) base
+                    const unsigned o = (unsigned)(oy * p.wo + ox) * (unsigned)p.cout + (unsigned)col;
                     float v = acc[mi][ni][e] * inv + bi;
                     if (p.scale) v = v * sc + sh;
-                    if (p.residual) v += p.residual[o];
+                    if (p.residual) v += res_b[o];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[o] = v;
+                    out_b[o] = v;
                 }
             }
     }
@@ -913,12 +917,13 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
     p.m = batch * p.ho * p.wo;
     p.k = ks * ks * cin;
     p.status = pram_status_ptr();
+    p.act_scale = pram_act_scale();
     int mi, wn;
     gemm::choose_tile(p.m, cout, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
     const _Float16* wh = (const _Float16*)wgt_hi;
     const _Float16* wl = (const _Float16*)wgt_lo;
-    const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    const float inv = 1.0f / (pram_act_scale() * w_scale);
 #define LAUNCHX3(MI_, WN_)                                                                                              \
     do {                                                                                                                \
         p.tiles_m = cdiv(p.m, gemmx3::Cfg<MI_, WN_>::BM);                                                               \
@@ -929,7 +934,7 @@ extern "C" int pram_conv2d_nhwc_x3_f32(const float* in, int batch, int h, int w,
     const char* halo_env = getenv("PRAM_CONV_HALO");      // "0": the per-tap staging kernel for every layer (profiling / the equality test; read per call)
     // PRAM_CONV_HALO: "0" = never, "w" = the 256-channel form only (what the 128-channel form buys is measured with it)
     if (ks == 3 && stride == 1 && (cout >= 256 || (cout == 128 && !(halo_env && halo_env[0] == 'w'))) && !(force && force[0] == 'n') &&
-        !(halo_env && halo_env[0] == '0')) {
+        !(halo_env && halo_env[0] == '0') && (long long)p.ho * p.wo * cout < (1ll << 31)) {      // (its epilogue: 32-bit offsets per map)
         const int tiles_x = cdiv(p.wo, halo::TW), tiles_y = cdiv(p.ho, halo::TH);
         p.tiles_m = batch * tiles_x * tiles_y;
         const bool narrow = cout <= 128;      // one 128-channel column tile
@@ -988,10 +993,11 @@ extern "C" int pram_conv2d_nhwc_x3_l2norm_f32(const float* in, int batch, int h,
     p.m = batch * p.ho * p.wo;
     p.k = ks * ks * cin;
     p.status = pram_status_ptr();
+    p.act_scale = pram_act_scale();
     p.tiles_m = cdiv(p.m, gemmx3::Cfg<2, 2>::BM);
     p.tiles_n = 1;
     hipLaunchKernelGGL((conv_x3_kernel<2, 2, true>), dim3(p.tiles_m), dim3(gemmx3::NT), 0, (hipStream_t)stream, p, (const _Float16*)wgt_hi,
-                       (const _Float16*)wgt_lo, 1.0f / (gemmx3::ACT_SCALE * w_scale));
+                       (const _Float16*)wgt_lo, 1.0f / (pram_act_scale() * w_scale));
     return pram_launch_status("pram_conv2d_nhwc_x3_l2norm_f32");
 }
 
@@ -1017,6 +1023,7 @@ extern "C" int pram_conv2d_nhwc_x3_planes(const float* in, int batch, int h, int
     p.m = batch * p.ho * p.wo;
     p.k = ks * ks * cin;
     p.status = pram_status_ptr();
+    p.act_scale = pram_act_scale();
     p.out_hi = (_Float16*)out_hi;
     p.out_lo = (_Float16*)out_lo;
     using CW = gemmx3w::Cfg<4, 2, 4>;
@@ -1029,7 +1036,7 @@ extern "C" int pram_conv2d_nhwc_x3_planes(const float* in, int batch, int h, int
     p.tiles_m = cdiv(p.m, CW::BM);
     p.tiles_n = cdiv(cout, CW::BN);
     hipLaunchKernelGGL((conv_x3w_kernel<4, 2, 4, true>), dim3(p.tiles_m * p.tiles_n), dim3(CW::NT), shm, (hipStream_t)stream, p,
-                       (const _Float16*)wgt_hi, (const _Float16*)wgt_lo, 1.0f / (gemmx3::ACT_SCALE * w_scale));
+                       (const _Float16*)wgt_hi, (const _Float16*)wgt_lo, 1.0f / (pram_act_scale() * w_scale));
     return pram_launch_status("pram_conv2d_nhwc_x3_planes");
 }
 
@@ -1286,7 +1293,7 @@ extern "C" int pram_conv3x3_grouped_planes_x3_f32(const void* in_hi, const void*
     PRAM_REQUIRE((size_t)batch * h * w * c < ((size_t)1 << 29), "pram_conv3x3_grouped_planes_x3_f32: at most 2^29 elements (32-bit buffer offsets)");
     if (batch == 0) return PRAM_OK;
     gx::Args p{(const _Float16*)in_hi, (const _Float16*)in_lo, out, (const _Float16*)w_hi, (const _Float16*)w_lo,
-               1.0f / (gemmx3::ACT_SCALE * w_scale), scale, shift, batch, h, w, c, relu, cdiv(w, gx::TW), cdiv(h, gx::TH)};
+               1.0f / (pram_act_scale() * w_scale), scale, shift, batch, h, w, c, relu, cdiv(w, gx::TW), cdiv(h, gx::TH)};
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gconv3x3_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gx::SMEM);

@@ -48,6 +48,7 @@ struct Args {
     unsigned int* status;
     int abl;      // profiling only (PRAM_C1_ABLATE): 1 = no conv1a blocks, 2 = no conv1b taps, 4 = no weight DMA after the first
     int nchw3;
+    float act_scale = gemmx3::ACT_SCALE;      // scale of the activation planes (pram_act_scale() at launch)
 };
 
 __device__ __forceinline__ int rowoff(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
                 }
                 if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 half4 hi, lo;
-                gemmx3::split4(v, gemmx3::ACT_SCALE, hi, lo, amax);
+                gemmx3::split4(v, p.act_scale, hi, lo, amax);
                 *reinterpret_cast<half4*>(&i_h[ip * 4]) = hi;
                 *reinterpret_cast<half4*>(&i_l[ip * 4]) = lo;
             }
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(c1::NT, 1) void conv1ab_x3_kernel(c1::Args p) {
             for (int e = 0; e < 16; ++e) {
                 const int ch = 32 * half + rowoff(e, h);
                 const float sc = p.sa[ch];
-                ca[e] = p.inva * sc * gemmx3::ACT_SCALE;
-                cc[e] = (p.ba[ch] * sc + p.ta[ch]) * gemmx3::ACT_SCALE;
+                ca[e] = p.inva * sc * p.act_scale;
+                cc[e] = (p.ba[ch] * sc + p.ta[ch]) * p.act_scale;
             }
 #pragma unroll 1
             for (int bi = (p.abl & 1) ? NBLK : wave; bi < NBLK; bi += NT / 64) {
@@ -259,14 +260,15 @@ extern "C" int pram_sfd2_conv1_x3_f32(const float* img, int batch, int h, int w,
     PRAM_REQUIRE(batch >= 0 && h > 0 && w > 0 && wa_scale > 0.f && wb_scale > 0.f, "pram_sfd2_conv1_x3_f32: bad sizes");
     if (batch == 0) return PRAM_OK;
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-    c1::Args p{img, out, (const _Float16*)wa_hi, (const _Float16*)wa_lo, 1.0f / (gemmx3::ACT_SCALE * wa_scale), ba, sa, ta,
-               (const _Float16*)wb_hi, (const _Float16*)wb_lo, 1.0f / (gemmx3::ACT_SCALE * wb_scale), bb, sb, tb,
+    c1::Args p{img, out, (const _Float16*)wa_hi, (const _Float16*)wa_lo, 1.0f / (pram_act_scale() * wa_scale), ba, sa, ta,
+               (const _Float16*)wb_hi, (const _Float16*)wb_lo, 1.0f / (pram_act_scale() * wb_scale), bb, sb, tb,
                batch, h, w, ho, wo, cdiv(wo, c1::TW), cdiv(ho, c1::TH), pram_status_ptr(), 0, img_nchw3 != 0};
 #ifdef PRAM_PROFILING      // ablations return garbage: compiled into profiling builds only (profiles/tools/build_variants.py ...:-DPRAM_PROFILING)
     { const char* e = getenv("PRAM_C1_ABLATE"); p.abl = e ? atoi(e) : 0; }
 #else
     p.abl = 0;
 #endif
+    p.act_scale = pram_act_scale();
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv1ab_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c1::SMEM_BYTES);

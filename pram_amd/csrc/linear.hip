@@ -44,6 +44,7 @@ struct LinArgs {
     float* row_ssq;
     int a0_f16, a1_f16;      // fp16 MFMA path: the A segment is fp16 in HBM (a0 / a1 point at halves, lda in halves) instead of fp32
     const float* ln_ssq; int ln_parts; const float* ln_gamma; const float* ln_beta; float ln_eps;
+    float act_scale = gemmx3::ACT_SCALE;      // split-fp16 path: scale of the A operand's planes (pram_act_scale() at launch)
 };
 
 // GELU(t) = t Phi(t) with the Gaussian tail written as s(|t|) = 0.5 erfc(|t| / sqrt 2) = 2^-q(|t|), q a degree-7 polynomial
@@ -108,19 +109,9 @@ __device__ __forceinline__ bool row_valid(const int* __restrict__ lens, int t_pa
 }
 
 // Shared epilogue (fp32 and fp16 main loops produce the same accumulator layout): bias, alpha, rotary, residual.
-// stage32: the (idle) staging memory of a kernel whose waves own >= EPI_WAVE_BYTES of it each — full tiles then leave as whole
-// 256-byte row segments (below, "rows through LDS")
-#ifndef PRAM_EPI_ROWS
-#define PRAM_EPI_ROWS 1
-#endif
-#ifndef PRAM_EPI_DEFER
-#define PRAM_EPI_DEFER 1
-#endif
-constexpr int EPI_WAVE_BYTES = 2 * 32 * 72 * 2;      // per wave: two 32 x 72 fp16 plane blocks, or one 32 x 68 fp32 block
-// DEFER: the lean instance for fp32-only outputs with a residual (no rotary, planes, fp16 copy or row statistics), see "Rows through LDS"
-template <int MI, int WN, bool DEFER>
-__device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&acc)[MI][2], float* out, int row0, int col0,
-                                                     int BM, int BN, _Float16* stage, float* stage32) {
+template <int MI, int WN>
+__device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[MI][2], float* out, int row0, int col0,
+                                                int BM, int BN, _Float16* stage = nullptr) {
     using gemm::acc_row;
     const int tid = threadIdx.x;
     const int mlast = p.m - 1, nlast = p.n - 1;
@@ -129,7 +120,7 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int cbase = col0 + wn * 64;
-    const bool rot = !DEFER && (p.flags & PRAM_LIN_ROTARY) && cbase < p.rot_cols;
+    const bool rot = (p.flags & PRAM_LIN_ROTARY) && cbase < p.rot_cols;
     const int c0 = cbase + r, c1 = cbase + 32 + r;
     const bool c0ok = c0 < p.n, c1ok = c1 < p.n;
     const int c0c = min(c0, nlast), c1c = min(c1, nlast);
@@ -142,14 +133,6 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
     // wave-uniform tile base (scalar registers) plus a 32-bit byte offset per lane — row e of a 32-row block is (e & 3) + 8 (e >> 2)
     // leading dimensions further, a scalar product — instead of a 64-bit multiply-add per element and row (48 quarter-rate
     // instructions per 32 stores before; the epilogue is vector-issue-bound, profiles/r05_gemm_epilogue.txt).
-    // Rows through LDS (round 6).  A lane owns one COLUMN of 16 rows, so the direct fp32 store of a 32 x 64 block is 32 dword
-    // instructions per lane (1 024 per 256 x 256 workgroup tile, 22 clocks each: a third of the tile's time with the matrix pipe
-    // idle, profiles/r05_gemm_epilogue.txt).  Full tiles instead transpose each block through the wave's own slice of the idle
-    // staging memory (32 ds_write_b32, 8 ds_read_b128) and store 16 bytes per lane, 256 contiguous bytes per row: 8 store
-    // instructions.  A residual that nothing else in the epilogue needs (no planes, no row statistics) is read the same way —
-    // 8 loads of 16 bytes — and added behind the transposition: the same last addition, the same bits.
-    const bool tstore = DEFER || (PRAM_EPI_ROWS && stage32 && full && out && (p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    constexpr bool defer_res = DEFER;
     const unsigned unit_alpha = p.alpha == 1.0f;
     float one = 1.0f;       // a 1.0 the optimiser cannot see through: fma(s, 1, -hi) stays an fma and selects v_fma_mixlo_f16
     asm volatile("" : "+s"(one));
@@ -176,8 +159,7 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
                 rs_[e] = p.rsin[rr];
             }
         }
-        if (defer_res) {
-        } else if (p.residual && full) {
+        if (p.residual && full) {
             const char* tile = reinterpret_cast<const char*>(p.residual + (size_t)(rbase + 32 * mi) * p.ldr + cbase);
             const unsigned lane_off = ((unsigned)(4 * h) * (unsigned)p.ldr + r) * 4u, ld4 = (unsigned)p.ldr * 4u;
 #pragma unroll
@@ -211,18 +193,11 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
                 v0 = e0;
                 v1 = o0;
             }
-            if (p.residual && !defer_res) { v0 += q0[e]; v1 += q1[e]; }
+            if (p.residual) { v0 += q0[e]; v1 += q1[e]; }
             q0[e] = v0;
             q1[e] = v1;
         }
-        float4 rres[8];
-        if (defer_res) {      // (requested here, behind the rotary / bias registers' lives: 32 more registers at the top of the block spill)
-            const char* tile = reinterpret_cast<const char*>(p.residual + (size_t)(rbase + 32 * mi) * p.ldr + cbase);
-            const unsigned lane_off = ((unsigned)(lane >> 4) * (unsigned)p.ldr + (lane & 15) * 4) * 4u, ld16 = (unsigned)p.ldr * 16u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) rres[j] = *reinterpret_cast<const float4*>(tile + lane_off + j * ld16);
-        }
-        if (!DEFER && p.row_ssq) {
+        if (p.row_ssq) {
             // Sum of squares of this wave's 64 columns of every row (lanes 0..31 / 32..63 hold the same rows' other columns),
             // one partial per 64-column block: every tile configuration has 64-column wave tiles, so a block's partial — and
             // the consumer's ascending sum over the blocks — is the same bits whichever tile ran (batch == B = 1).
@@ -268,8 +243,7 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
             const int row = rbase + acc_row(mi, e_own, h);
             if ((lane & 1) == 0 && row < p.m && cbase < p.n) p.row_ssq[(size_t)(cbase >> 6) * p.m + row] = v1;
         }
-        if (DEFER) {
-        } else if (p.vt_hi && cbase >= p.vt_col0) {
+        if (p.vt_hi && cbase >= p.vt_col0) {
             // Value head of the projection: straight into the V^T planes.  The accumulator layout IS the key permutation of
             // attention_x3.hip (pos_of_key): registers 8g .. 8g+7 of a lane are eight consecutive positions of one head dim, so a
             // lane writes 16 bytes per plane, head dim and register half.  Tokens beyond their sequence's length become zeros
@@ -410,27 +384,7 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
             }
         }
         if (out == nullptr) continue;
-        if (tstore) {
-            constexpr int LD = 68;      // floats per staged row: 272 B, 16-byte aligned, the lane halves' rows 16 banks apart
-            float* s32 = reinterpret_cast<float*>(reinterpret_cast<char*>(stage32) + wave * EPI_WAVE_BYTES);
-            asm volatile("" ::: "memory");      // the wave's slice may just have carried this block's planes (fp16 accesses)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = acc_row(0, e, h);
-                s32[rr * LD + r] = q0[e];
-                s32[rr * LD + 32 + r] = q1[e];
-            }
-            char* tile = reinterpret_cast<char*>(out + (size_t)(rbase + 32 * mi) * p.ldo + cbase);
-            const unsigned lane_off = ((unsigned)(lane >> 4) * (unsigned)p.ldo + (lane & 15) * 4) * 4u, ld16 = (unsigned)p.ldo * 16u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float4 v = *reinterpret_cast<const float4*>(s32 + ((lane >> 4) + 4 * j) * LD + (lane & 15) * 4);
-                if (defer_res) { v.x += rres[j].x; v.y += rres[j].y; v.z += rres[j].z; v.w += rres[j].w; }
-                *reinterpret_cast<float4*>(tile + lane_off + j * ld16) = v;
-            }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        } else if (full) {   // block-uniform fast path: no per-element predicates
+        if (full) {   // block-uniform fast path: no per-element predicates
             char* tile = reinterpret_cast<char*>(out + (size_t)(rbase + 32 * mi) * p.ldo + cbase);
             const unsigned lane_off = ((unsigned)(4 * h) * (unsigned)p.ldo + r) * 4u, ld4 = (unsigned)p.ldo * 4u;
 #pragma unroll
@@ -451,17 +405,6 @@ __device__ __forceinline__ void linear_epilogue_impl(const LinArgs& p, f32x16 (&
         }
     }
     if (p.out16_lo) x3_range_flag(p.status, emax);
-}
-
-template <int MI, int WN>
-__device__ __forceinline__ void linear_epilogue(const LinArgs& p, f32x16 (&acc)[MI][2], float* out, int row0, int col0,
-                                                int BM, int BN, _Float16* stage = nullptr, float* stage32 = nullptr) {
-    // (workgroup-uniform) the lean instance: full tile, fp32 output + residual and nothing else
-    const bool lean = PRAM_EPI_ROWS && PRAM_EPI_DEFER && stage32 && out && p.residual && (row0 + BM <= p.m) && (col0 + BN <= p.n) && !p.lens &&
-                      !(p.flags & PRAM_LIN_ROTARY) && !p.row_ssq && !p.out16 && !p.vt_hi && ((p.ldo | p.ldr) & 3) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(p.residual)) & 15) == 0;
-    if (lean) linear_epilogue_impl<MI, WN, true>(p, acc, out, row0, col0, BM, BN, stage, stage32);
-    else linear_epilogue_impl<MI, WN, false>(p, acc, out, row0, col0, BM, BN, stage, stage32);
 }
 
 template <int MI, int WN, int BKT>
@@ -626,9 +569,9 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
 #pragma unroll
         for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + 32 * pp, K) : 0.f;
         __syncthreads();
-        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax, xf);
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, p.act_scale, acc, amax, xf);
     } else {
-        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, ACT_SCALE, acc, amax);
+        mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, p.act_scale, acc, amax);
     }
     x3_range_flag(p.status, amax);
 #pragma unroll
@@ -759,7 +702,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             return (plane ? a0l : a0h) + rc * alda0 + k;
         };
         float amax = 0.f;      // planes in: nothing is split here
-        mainloop<MI, WM, WN, true, ABL, (DMA ? 2 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax);
+        mainloop<MI, WM, WN, true, ABL, (DMA ? 2 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, p.act_scale, acc, amax);
     } else {
         const float* arow0[C::PA];
         const float* arow1[C::PA];
@@ -786,9 +729,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
 #pragma unroll
             for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + C::RA * pp, K) : 0.f;
             __syncthreads();
-            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, gemmx3::ACT_SCALE, acc, amax, xf);
+            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, p.act_scale, acc, amax, xf);
         } else {
-            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, ABL == 128 ? 1 : (ABL == 256 && (blockIdx.x & 1) && blockIdx.x < 256) ? K / BK / 2 : K / BK, gemmx3::ACT_SCALE, acc, amax);
+            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, ABL == 128 ? 1 : (ABL == 256 && (blockIdx.x & 1) && blockIdx.x < 256) ? K / BK / 2 : K / BK, p.act_scale, acc, amax);
         }
         x3_range_flag(p.status, amax);
     }
@@ -813,8 +756,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] *= inv;
     // the staging memory is idle now (the main loop ends on a barrier): the plane epilogue transposes through it
     _Float16* stage = (p.out16_lo && p.n % 8 == 0 && p.ldo16 % 8 == 0) ? reinterpret_cast<_Float16*>(smem_raw) : nullptr;
-    static_assert(sizeof(Smem<MI, WM, WN>) >= (size_t)(C::NT / 64) * EPI_WAVE_BYTES, "a slice of the staging memory per wave");
-    linear_epilogue<MI, WN>(p, acc, p.out, ABL == 512 ? 0 : row0, col0, BM, BN, stage, reinterpret_cast<float*>(smem_raw));      // (512, profiling: every row tile stores to rows 0..255: the stores stay in the L2)
+    linear_epilogue<MI, WN>(p, acc, p.out, ABL == 512 ? 0 : row0, col0, BM, BN, stage);      // (512, profiling: every row tile stores to rows 0..255: the stores stay in the L2)
     if constexpr ((ABL & 4) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) atomicAdd(&gemmx3w::prof[6], (unsigned long long)__builtin_readcyclecounter() - te0);
@@ -1018,15 +960,16 @@ extern "C" int pram_linear_x3p_f32(const void* a0_hi, const void* a0_lo, int lda
         PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_x3p_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
     if (m == 0) return PRAM_OK;
     LinArgs p{nullptr, lda0, k0, nullptr, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
-              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE};
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, pram_act_scale()};
     PlaneArgs a{(const _Float16*)a0_hi, (const _Float16*)a0_lo, lda0, (const _Float16*)a1_hi, (const _Float16*)a1_lo, lda1};
     p.status = pram_status_ptr();
+    p.act_scale = pram_act_scale();
     int mi, wn;
     gemm::choose_tile(m, n, &mi, &wn);
     hipStream_t st = (hipStream_t)stream;
     const _Float16* wh = (const _Float16*)w_hi;
     const _Float16* wl = (const _Float16*)w_lo;
-    const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    const float inv = 1.0f / (pram_act_scale() * w_scale);
     if (launch_linear_x3_wide<true>(p, a, wh, wl, inv, st)) return pram_launch_status("pram_linear_x3p_f32");
     if (wn == 2) { if (mi == 2) launch_linear_x3p_t<2, 2>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 2>(p, a, wh, wl, inv, st); }
     else         { if (mi == 2) launch_linear_x3p_t<2, 1>(p, a, wh, wl, inv, st); else launch_linear_x3p_t<1, 1>(p, a, wh, wl, inv, st); }
@@ -1065,9 +1008,10 @@ static int linear_x3_impl(const LnIo* ln, const VtOut* vt, const int* lens, int 
         PRAM_REQUIRE(rot_cos && rot_sin && rot_cols % 64 == 0, "pram_linear_x3_f32: rotary needs cos/sin and rot_cols %% 64 == 0");
     if (m == 0) return PRAM_OK;
     LinArgs p{a0, lda0, k0, a1, lda1, k1, nullptr, bias, residual, ldr, out, ldo, m, n, alpha, flags,
-              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, gemmx3::ACT_SCALE, lens, t_pad};
+              rot_cos, rot_sin, rot_cols, 0, 0, 0, 0, 0, out_hi, ldo16, out_lo, pram_act_scale(), lens, t_pad};
     PRAM_REQUIRE(!lens || t_pad > 0, "pram_linear_x3_f32: lens needs t_pad > 0");
     p.status = pram_status_ptr();
+    p.act_scale = pram_act_scale();
     if (ln) {
         PRAM_REQUIRE(!(ln->ssq_out && (out_hi || vt)), "pram_linear_x3_ssq_f32: row sums go with an fp32 output");
         p.row_ssq = ln->ssq_out;
@@ -1090,7 +1034,7 @@ static int linear_x3_impl(const LnIo* ln, const VtOut* vt, const int* lens, int 
     hipStream_t st = (hipStream_t)stream;
     const _Float16* wh = (const _Float16*)w_hi;
     const _Float16* wl = (const _Float16*)w_lo;
-    const float inv = 1.0f / (gemmx3::ACT_SCALE * w_scale);
+    const float inv = 1.0f / (pram_act_scale() * w_scale);
     {
         PlaneArgs none{nullptr, nullptr, 0, nullptr, nullptr, 0};
         if (launch_linear_x3_wide<false>(p, none, wh, wl, inv, st)) return pram_launch_status("pram_linear_x3_f32");
@@ -1286,11 +1230,11 @@ extern "C" int pram_bgemm_nt_x3p_f32(const void* a_hi, const void* a_lo, int lda
                  "pram_bgemm_nt_x3p_f32: need k %% 32 == 0, lda %% 8 == 0, ldb == k, plane strides %% 8 == 0");
     if (batch == 0 || m_max == 0 || n_max == 0) return PRAM_OK;
     LinArgs p{nullptr, lda, k, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, c, ldc, m_max, n_max, alpha, 0,
-              nullptr, nullptr, 0, stride_a, stride_b, stride_c, 0, 0, nullptr, 0, nullptr, gemmx3::ACT_SCALE};
+              nullptr, nullptr, 0, stride_a, stride_b, stride_c, 0, 0, nullptr, 0, nullptr, pram_act_scale()};
     PlaneArgs a{(const _Float16*)a_hi, (const _Float16*)a_lo, lda, nullptr, nullptr, 0};
     const _Float16* wh = (const _Float16*)b_hi;
     const _Float16* wl = (const _Float16*)b_lo;
-    const float inv = 1.0f / (gemmx3::ACT_SCALE * gemmx3::ACT_SCALE);
+    const float inv = 1.0f / (pram_act_scale() * pram_act_scale());
     hipStream_t st = (hipStream_t)stream;
     if (launch_linear_x3_wide<true>(p, a, wh, wl, inv, st, batch)) return pram_launch_status("pram_bgemm_nt_x3p_f32");
     int mi, wn;

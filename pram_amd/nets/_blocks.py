@@ -199,18 +199,36 @@ def with_model_precision(fn):
     @functools.wraps(fn)
     def wrapper(self, *a, **k):
         with ops.precision_scope(getattr(self, "precision", None)):
-            # range guard of the split-fp16 path (ops.guarded_call): a value the format cannot carry re-runs the call on the
-            # exact-fp32 kernels (or raises) instead of coming back as NaN-derived indices
+            # range guard of the split-fp16 path (ops.guarded_call): a value the planes cannot carry first lowers this model's
+            # activation scale (self.act_scale, kept) and re-runs; beyond every scale the call re-runs on the exact-fp32 kernels
+            # (or raises) instead of coming back as NaN-derived indices
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 return fn(self, *a, **k)      # raises the "no CPU path" error itself
-            return ops.guarded_call(lambda: fn(self, *a, **k), dev)
+
+            def call():
+                ops.note_model_ran(self)
+                with ops.act_scale_scope(getattr(self, "act_scale", None)):      # read at every (re-)run: the guard may have lowered it
+                    return fn(self, *a, **k)
+            return ops.guarded_call(call, dev)
     return wrapper
 
 
 class PackedCache:
     """Mixin: device-side packed weights, rebuilt after load_state_dict / .to() / .cuda(); per-model MFMA path."""
     precision: Optional[str] = None      # "f32" | "x3" | "f16"; None follows ops.gemm_prec() / ops.attn_prec()
+    # split-fp16 path: the activation planes of this model carry value * act_scale (ops: "activation scale").  16 covers
+    # |x| < 4094.97; the range guard divides it by 16 when an activation does not fit and the model keeps the result — or set it
+    # up front with set_act_scale() / calibrate_act_scale() for a checkpoint whose range is known.
+    act_scale: float = 16.0
+
+    def set_act_scale(self, s: float):
+        s = float(s)
+        import math
+        if not (s > 0 and math.log2(s) == int(math.log2(s)) and 2.0 ** -12 <= s <= 16.0):
+            raise ValueError(f"act_scale {s!r}: expected a power of two in [2^-12, 16]")
+        self.act_scale = s
+        return self
 
     def set_precision(self, p: Optional[str]):
         self.precision = None if p is None else ops._check_precision(p)

@@ -529,26 +529,96 @@ class guard_scope:
         return False
 
 
+# ---- activation scale of the split-fp16 path (include/pram_hip.h, "activation scale").  The planes carry value * s, s = 16 by
+# default (range |x| < 4094.97).  A model whose activations are larger — trained checkpoints — does not have to leave the split
+# path: it lowers s (a power of two; s = 1 carries |x| < 65520, s = 1/16 a million) and keeps the same 22-bit significand.  The
+# scale is a property of the MODEL (PackedCache.act_scale, applied around its forward by nets/_blocks.with_model_precision) and
+# is found by the range guard itself: a tripped guard first lowers the scale of the models that ran (sticky: the cliff is met
+# once) and re-runs on the split kernels; only a value no scale can carry goes to the exact-fp32 kernels.
+ACT_SCALE_DEFAULT = 16.0
+ACT_SCALE_MIN = 2.0 ** -8
+guard_events = {"rescaled": 0, "f32_fallback": 0}      # what the range guard did so far in this process (tests / bench read it)
+
+
+def current_act_scale() -> float:
+    return float(_lib.load().pram_x3_set_act_scale(0.0))
+
+
+class act_scale_scope:
+    """``with ops.act_scale_scope(s): ...`` — the split-fp16 launches of this thread inside the block carry their activation planes
+    as value * s (None: no change).  Producers and consumers of planes must run under the same scale."""
+
+    def __init__(self, s: Optional[float]):
+        self.s = None if s is None else float(s)
+
+    def __enter__(self):
+        self.saved = None
+        if self.s is not None:
+            self.saved = float(_lib.load().pram_x3_set_act_scale(self.s))
+            if self.saved < 0:
+                raise _lib.PramHipError(f"activation scale {self.s!r}: expected a power of two in [2^-12, 16]")
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            _lib.load().pram_x3_set_act_scale(self.saved)
+        return False
+
+
+def _ran_models():
+    """models (PackedCache) whose guarded forward ran inside the current outermost guarded call of this thread"""
+    return _tl("ran", None)
+
+
+def note_model_ran(model) -> None:
+    ran = _tl("ran", None)
+    if ran is not None and all(m is not model for m in ran):
+        ran.append(model)
+
+
 def guarded_call(fn, device):
     """Run ``fn()`` (a model entry point) under the range guard: only the OUTERMOST guarded call of a thread checks the status
     word, after its last launch, and only if a split-fp16 kernel was launched on the device since the word was last read; nothing
-    is checked while a stream is capturing (a hipGraph cannot synchronise: GraphedPipeline checks after the replay)."""
+    is checked while a stream is capturing (a hipGraph cannot synchronise: GraphedPipeline checks after the replay).
+    A tripped guard ("fallback", the default) first divides the activation scale of every model that ran inside the call by 16
+    (down to ACT_SCALE_MIN; the models keep it) and re-runs on the split kernels; when no scale is left to give, or nothing that
+    ran has one, the call re-runs on the exact-fp32 kernels."""
     depth = _tl("depth", 0)
+    if depth == 0:
+        _tls.ran = []
     _tls.depth = depth + 1
     try:
         out = fn()
     finally:
         _tls.depth = depth
     policy = guard_policy()
-    if depth != 0 or policy == "deferred" or not x3_launched(device):
+    if depth != 0:
+        return out
+    ran, _tls.ran = _tl("ran", None) or [], None
+    if policy == "deferred" or not x3_launched(device):
         return out
     if policy not in X3_GUARDS:
         raise _lib.PramHipError(f"unknown x3 guard {policy!r} (expected one of {X3_GUARDS})")
     if torch.cuda.is_current_stream_capturing() or not x3_range_exceeded(device):
         return out
     if policy == "raise":
-        raise _lib.PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 (fp16(16 x) overflows) — re-run with "
-                                "precision 'f32' (or PRAM_X3_GUARD=fallback)")
+        raise _lib.PramHipError("split-fp16 path: an activation beyond the range of its planes (|x| >= 65520 / act_scale; "
+                                "4094.97 at the default scale) — lower the models' act_scale, or re-run with precision 'f32' "
+                                "(PRAM_X3_GUARD=fallback does both by itself)")
+    while True:
+        scalable = [m for m in ran if getattr(m, "act_scale", None) and m.act_scale / 16.0 >= ACT_SCALE_MIN]
+        if not scalable:
+            break
+        for m in scalable:
+            m.act_scale = m.act_scale / 16.0
+        guard_events["rescaled"] += 1
+        _tls.depth, _tls.ran = depth + 1, None
+        try:
+            out = fn()
+        finally:
+            _tls.depth = depth
+        if not x3_range_exceeded(device):
+            return out
+    guard_events["f32_fallback"] += 1
     _tls.depth = depth + 1
     try:
         with forced_precision("f32"):

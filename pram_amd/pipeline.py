@@ -350,17 +350,17 @@ class GraphedPipeline:
             if guard == "raise":
                 from ._lib import PramHipError
                 raise PramHipError("split-fp16 path: an activation beyond |x| < 4094.97 in the replayed step")
-            # The captured buffers (self.out, self.record) hold the overflowed replay: the result of THIS call is the eager exact-fp32
-            # re-run returned below.  The re-run gets the CAPTURED inputs (self.images / self.ref were just refreshed from the
+            # The captured buffers (self.out, self.record) hold the overflowed replay: the result of THIS call is the eager re-run
+            # returned below, under the pipeline's own policy — "fallback" lowers the activation scale of the models that ran
+            # (they keep it: a graph captured afterwards replays in range; THIS graph keeps tripping and re-running eagerly until
+            # it is rebuilt) and only goes to the exact-fp32 kernels when no scale carries the values.  The re-run gets the CAPTURED inputs (self.images / self.ref were just refreshed from the
             # arguments: `ref=None` means "the captured reference sets", not "no matcher"), and its record is copied INTO the
             # captured record tensor — self.record stays the buffer every later replay writes, so a caller that keeps reading
-            # g.record after replay() sees that replay's record, not this call's.  The re-run cannot overflow (no
-            # split kernels under forced_precision), hence "deferred".  One status word serves the whole device: a caller that
+            # g.record after replay() sees that replay's record, not this call's.  One status word serves the whole device: a caller that
             # keeps OTHER replays in flight on other streams must use replay() and check ops.x3_range_exceeded() itself once they
             # are done — the reset here is not ordered against them.
-            with ops.forced_precision("f32"):
-                out = self.pipe.run(self.images, self.ref, self.stages, guard="deferred")
-                if self.with_record:
-                    self.record.copy_(QueryPipeline.pack_record(out))
+            out = self.pipe.run(self.images, self.ref, self.stages, guard=guard)
+            if self.with_record:
+                self.record.copy_(QueryPipeline.pack_record(out))
             return out
         return self.out

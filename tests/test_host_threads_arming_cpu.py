@@ -5,6 +5,7 @@ import sys
 import threading
 from pathlib import Path
 
+import pytest
 import torch
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -106,7 +107,7 @@ from pram_amd import _lib
 L = _lib.load()
 helpers = {"pram_hip_version", "pram_last_error", "pram_fill_u32", "pram_linear_x3_ssq_parts", "pram_attention_x3_is_split",
            "pram_attention_x3_mfma_per_tile", "pram_attention_x3_set_chunk_keys", "pram_attention_x3_set_p_split",
-           "pram_attention_x3_set_split_target"}
+           "pram_attention_x3_set_split_target", "pram_x3_set_act_scale"}
 for name, (res, args) in sorted(_lib._SIGS.items()):
     vals = [None if a is _lib.P else (0.0 if a is _lib.F else 0) for a in args]
     r = getattr(L, name)(*vals)
@@ -118,3 +119,30 @@ print("ok", len(_lib._SIGS))
 """ % str(ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_activation_scale_setter_is_validated_and_thread_local():
+    """pram_x3_set_act_scale: powers of two in [2^-12, 16] only, query with 0, per host thread (no GPU needed: nothing launches)."""
+    import threading
+    from pram_amd import _lib, ops
+    L = _lib.load()
+    assert L.pram_x3_set_act_scale(0.0) == 16.0
+    assert L.pram_x3_set_act_scale(3.0) == -1.0 and L.pram_x3_set_act_scale(32.0) == -1.0 and L.pram_x3_set_act_scale(2.0 ** -13) == -1.0
+    assert L.pram_x3_set_act_scale(0.0) == 16.0                       # refused values change nothing
+    seen = {}
+
+    def other():
+        seen["before"] = L.pram_x3_set_act_scale(0.0)
+        L.pram_x3_set_act_scale(0.25)
+        seen["after"] = L.pram_x3_set_act_scale(0.0)
+
+    with ops.act_scale_scope(1.0):
+        assert ops.current_act_scale() == 1.0
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert ops.current_act_scale() == 1.0                         # the other thread's setting is its own
+    assert seen == {"before": 16.0, "after": 0.25} and ops.current_act_scale() == 16.0
+    with pytest.raises(_lib.PramHipError):
+        with ops.act_scale_scope(5.0):
+            pass
