@@ -673,16 +673,19 @@ class Job:
         lane.wait_stream(main_s)          # a captured record buffer is rewritten by the lane's next replay: not before the gather read it
         return full
 
-    def timed(self, steps, warmup, sync_all, ahead=0):
+    def timed(self, steps, warmup, sync_all, ahead=0, min_seconds=0.0):
         """ahead > 0 (long runs): the host never runs more than `ahead` steps in front of the device (it waits for the event behind
-        step i - ahead before issuing step i: no bubble, bounded queue and allocator footprint)."""
+        step i - ahead before issuing step i: no bubble, bounded queue and allocator footprint).  min_seconds: keep issuing steps
+        (beyond `steps`) until that much wall time has passed; self.steps_done says how many ran."""
         for _ in range(warmup):
             self.step()
         sync_all()
         t0 = time.perf_counter()
         rec = None
         evs = []
-        for i in range(steps):
+        i = 0
+        while i < steps or (min_seconds and time.perf_counter() - t0 < min_seconds):
+            i += 1
             rec = self.step()
             if ahead:
                 lane = self.lanes[(self.issued - 1) % len(self.lanes)] if self.lanes else torch.cuda.current_stream(self.dev)
@@ -692,6 +695,7 @@ class Job:
                 if len(evs) > ahead:
                     evs.pop(0).synchronize()
         sync_all()
+        self.steps_done = i
         return time.perf_counter() - t0, rec
 
 
@@ -742,7 +746,7 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=4, help="CPU-baseline sample size (0 = skip)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate (kernel profiling runs)")
     ap.add_argument("--alt", default="auto", choices=["auto", "on", "off"],
-                    help="also time, in the same run (3 steps each), AdaGML, the exact-fp32 path, the secondary 512 x 1024 matcher "
+                    help="also time, in the same run (6 steps each), AdaGML, the exact-fp32 path, the secondary 512 x 1024 matcher "
                          "shape and the one-query latency, and report them as 'alt' (auto: on for the default 1-GPU configuration)")
     ap.add_argument("--attn-chunk-keys", type=int, default=None,
                     help="keys per chunk of the split-fp16 attention (pram_attention_x3_set_chunk_keys; default: the library's 4096 = one chunk for every shipped shape, "
@@ -923,7 +927,7 @@ def main():
 
         only = [x for x in os.environ.get("PRAM_BENCH_ALTS", "").split(",") if x]      # profiling: a subset, in the usual order
 
-        def alt_run(name, note, steps_=3, warm_=2, p_split=None, chunk=None, parity_f16=False, parity_q=0, sustain_s=0.0, **kw):
+        def alt_run(name, note, steps_=6, warm_=4, p_split=None, chunk=None, parity_f16=False, parity_q=0, sustain_s=0.0, **kw):
             if only and name not in only:
                 return
             cfg = dict(matcher_name=args.matcher, kpts=args.kpts, n_class=args.n_class, stages=args.stages, inflight=inflight,
@@ -944,13 +948,13 @@ def main():
                 smp = None
                 if sustain_s:
                     # a run of >= sustain_s seconds over rotating batches with the socket power / shader clock sampled across it
-                    steps_ = max(steps_, int(sustain_s * 1e3 / (dt / steps * 1e3) * Bq / B) + 1)
                     smp = PowerSampler(dev.index if dev.index is not None else 0)
                     for _ in range(warm_):
                         j.step()
                     sync_all()
                     smp.start()
-                    t, _ = j.timed(steps_, 0, sync_all, ahead=8)
+                    t, _ = j.timed(steps_, 0, sync_all, ahead=8, min_seconds=sustain_s)
+                    steps_ = j.steps_done
                 else:
                     t, _ = j.timed(steps_, warm_, sync_all)
                 hit = ops.x3_range_exceeded(dev) if ops.x3_launched(dev) else False

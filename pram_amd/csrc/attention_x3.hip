@@ -991,11 +991,15 @@ __global__ __launch_bounds__(NWV * 64, (NWV == NW && MODE != 1) ? 2 : 1) void at
     }
 }
 
-// Split mode, second step: one wave per (query row, head), one lane per output dim; the left fold over the key chunks of that
-// row in chunk order — fold_weights / fold_value exactly as the fused kernel (MODE 1) applies them.
+// Split mode, second step: the left fold over the key chunks of a (query row, head) in chunk order — fold_weights / fold_value
+// exactly as the fused kernel (MODE 1) applies them.  One lane per four output dims (16 lanes per (row, head)); the chunks' partial
+// outputs and log-sums are all requested BEFORE the first fold (up to CMAX chunks at a time: independent loads, one round trip) —
+// the first version asked for chunk c + 1 only after folding chunk c, one L2 round trip per chunk on the one-query path's critical
+// path (9 us per launch for a 4-chunk fold, profiles/r05_latency_step_anatomy.md).
 __global__ __launch_bounds__(256) void combine_x3_kernel(ArgsX p) {
-    const int lane = threadIdx.x & 63;
-    const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, qrow, head)
+    constexpr int CMAX = 8;
+    const int sub = threadIdx.x & 15;                                           // dims 4 sub .. 4 sub + 3
+    const long long unit = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);     // (b, qrow, head)
     const long long units = (long long)p.batch * p.m_max * p.heads;
     if (unit >= units) return;
     const int head = (int)(unit % p.heads);
@@ -1007,17 +1011,35 @@ __global__ __launch_bounds__(256) void combine_x3_kernel(ArgsX p) {
     if (qrow >= qlen || klen <= 0) return;            // empty key set: the attention kernel wrote the zeros itself
     const int nchunk = (klen + p.chunk_tiles * BKV - 1) / (p.chunk_tiles * BKV);
     const size_t li = ((size_t)b * p.heads + head) * p.m_max + qrow;
-    float ot = 0.f, lt = -INFINITY;
-    for (int c = 0; c < nchunk; ++c) {
-        const float oc = p.part_o[((size_t)c * p.batch * p.m_max + row) * (p.heads * D) + head * D + lane];
-        const float lc = p.part_l[(size_t)c * p.batch * p.heads * p.m_max + li];
-        float at, ac, lnew;
-        fold_weights(lt, lc, &at, &ac, &lnew);
-        ot = fold_value(ot, oc, at, ac);
-        lt = lnew;
+    const size_t ostride = (size_t)p.batch * p.m_max * (p.heads * D), lstride = (size_t)p.batch * p.heads * p.m_max;
+    const float* po = p.part_o + (size_t)row * (p.heads * D) + head * D + 4 * sub;
+    const float* pl = p.part_l + li;
+    float4 ot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lt = -INFINITY;
+    for (int c0 = 0; c0 < nchunk; c0 += CMAX) {
+        float4 oc[CMAX];
+        float lc[CMAX];
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) {
+            const int c = min(c0 + i, nchunk - 1);      // (clamped: a legal address, the value is not used)
+            oc[i] = *reinterpret_cast<const float4*>(po + (size_t)c * ostride);
+            lc[i] = pl[(size_t)c * lstride];
+        }
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) {
+            if (c0 + i < nchunk) {
+                float at, ac, lnew;
+                fold_weights(lt, lc[i], &at, &ac, &lnew);
+                ot.x = fold_value(ot.x, oc[i].x, at, ac);
+                ot.y = fold_value(ot.y, oc[i].y, at, ac);
+                ot.z = fold_value(ot.z, oc[i].z, at, ac);
+                ot.w = fold_value(ot.w, oc[i].w, at, ac);
+                lt = lnew;
+            }
+        }
     }
-    p.out[(size_t)row * p.ldo + head * D + lane] = ot;
-    if (p.lse2 && lane == 0) p.lse2[li] = lt;
+    *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldo + head * D + 4 * sub) = ot;
+    if (p.lse2 && sub == 0) p.lse2[li] = lt;
 }
 
 // V^T planes for attention_x3_kernel: [seq][head][64 dims][tv positions] fp16, position = 64 * (t / 64) + pos_of_key(t % 64),
@@ -1389,7 +1411,7 @@ extern "C" int pram_attention_x3_f32(const void* q_hi, const void* q_lo, int ldq
 #undef PRAM_LAUNCH_PIPE
 #undef PRAM_LAUNCH_PIPE_
         const long long rows = (long long)batch * m_max * heads;
-        hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(combine_x3_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, p);
         return pram_launch_status("pram_attention_x3_f32");
     }
     return pram_launch_status("pram_attention_x3_f32");

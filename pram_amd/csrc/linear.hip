@@ -85,9 +85,19 @@ struct LnGeluXf {
 };
 
 // rstd of row `row` from the first GEMM's partial sums of squares (fixed order: deterministic)
+// (the partials are all requested before the first is added — up to 16 at a time, hidden <= 1024 — one memory round trip instead of
+//  one per partial in the prologue of every workgroup; the sum keeps its ascending order: same bits)
 __device__ __forceinline__ float ln_rstd(const LinArgs& p, int row, int K) {
+    constexpr int QMAX = 16;
     float s = 0.f;
-    for (int q = 0; q < p.ln_parts; ++q) s += p.ln_ssq[(size_t)q * p.m + row];
+    for (int q0 = 0; q0 < p.ln_parts; q0 += QMAX) {
+        float v[QMAX];
+#pragma unroll
+        for (int i = 0; i < QMAX; ++i) v[i] = p.ln_ssq[(size_t)min(q0 + i, p.ln_parts - 1) * p.m + row];
+#pragma unroll
+        for (int i = 0; i < QMAX; ++i)
+            if (q0 + i < p.ln_parts) s += v[i];
+    }
     return 1.0f / sqrtf(s / (float)K + p.ln_eps);
 }
 
@@ -563,11 +573,22 @@ __global__ __launch_bounds__(gemmx3::NT, 2) void linear_x3_kernel(LinArgs p, con
     f32x16 acc[MI][2];
     float amax = 0.f;
     if constexpr (LNA) {
-        for (int i = tid; i < K; i += NT) { lngb[i] = p.ln_gamma[i]; lngb[K + i] = p.ln_beta[i]; }
+        // prologue loads all in flight together (gamma | beta, the rows' partial sums of squares): unpredicated, clamped addresses
+        {
+            float gv[4], bv[4];      // K <= 1024, NT = 256
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = min(tid + NT * j, K - 1); gv[j] = p.ln_gamma[i]; bv[j] = p.ln_beta[i]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (tid + NT * j < K) { lngb[tid + NT * j] = gv[j]; lngb[K + tid + NT * j] = bv[j]; }
+        }
         LnGeluXf<C::PA> xf;
         xf.gb = lngb; xf.K = K; xf.kq = akq;
 #pragma unroll
-        for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + 32 * pp, K) : 0.f;
+        for (int pp = 0; pp < C::PA; ++pp) {
+            const float rs = ln_rstd(p, min(row0 + arow + 32 * pp, mlast), K);
+            xf.rstd[pp] = ((rowok >> pp) & 1u) ? rs : 0.f;
+        }
         __syncthreads();
         mainloop<MI, WN>(smem, adv, la, oka, lb, okb, (K + BK - 1) / BK, p.act_scale, acc, amax, xf);
     } else {
@@ -723,11 +744,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
         auto aptr = [](int, int, int) -> const _Float16* { return nullptr; };
         float amax = 0.f;
         if constexpr (LNA) {
-            for (int i = tid; i < K; i += C::NT) { lngb[i] = p.ln_gamma[i]; lngb[K + i] = p.ln_beta[i]; }
+            // prologue loads all in flight together, as in linear_x3_kernel (K <= 1024, 512 threads: two rounds of gamma | beta)
+            {
+                float gv[2], bv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { const int i = min(tid + C::NT * j, K - 1); gv[j] = p.ln_gamma[i]; bv[j] = p.ln_beta[i]; }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (tid + C::NT * j < K) { lngb[tid + C::NT * j] = gv[j]; lngb[K + tid + C::NT * j] = bv[j]; }
+            }
             LnGeluXf<C::PA> xf;
             xf.gb = lngb; xf.K = K; xf.kq = akq;
 #pragma unroll
-            for (int pp = 0; pp < C::PA; ++pp) xf.rstd[pp] = ((rowok >> pp) & 1u) ? ln_rstd(p, row0 + arow + C::RA * pp, K) : 0.f;
+            for (int pp = 0; pp < C::PA; ++pp) {
+                const float rs = ln_rstd(p, min(row0 + arow + C::RA * pp, mlast), K);
+                xf.rstd[pp] = ((rowok >> pp) & 1u) ? rs : 0.f;
+            }
             __syncthreads();
             mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, p.act_scale, acc, amax, xf);
         } else {
@@ -928,6 +960,11 @@ bool launch_linear_x3_wide(LinArgs& p, PlaneArgs& a, const _Float16* wh, const _
     // the 256-row tiles lose when their last round is mostly empty — 32 768 x 768 (SegNetViT's q | k | v projection) is 384 tiles =
     // 2 rounds against 768 half tiles = 3 x 0.55 rounds.
     const bool use256 = force ? (force[1] == '2') : (big >= 224 && 100 * cdiv((int)big, 256) <= 55 * cdiv((int)small, 256));
+#ifdef PRAM_PROFILING
+    if constexpr (!APLANES) {
+        if (force && force[0] == 'f') { launch_linear_x3w_t<2, 1, 8, false>(p, a, wh, wl, inv, st, batch); return true; }      // full-row probe: 64 x 512 tiles
+    }
+#endif
     if (use256) launch_linear_x3w_t<4, 2, 4, APLANES>(p, a, wh, wl, inv, st, batch);
     else launch_linear_x3w_t<2, 2, 4, APLANES>(p, a, wh, wl, inv, st, batch);
     return true;

@@ -53,6 +53,25 @@ def test_bench_alt_matcher_pattern_and_upload_in_step(hip_lib):
     assert alt["h2d_in_step"]["queries_per_s"] > 0
 
 
+def test_bench_alt_sustained_and_activation_scale(hip_lib):
+    """Round 6's `alt` entries on a small batch: `sustained` (a run of seconds over rotating DISTINCT batches with a power / clock
+    trace and its ratio to the headline) and `act_scale_1` (every model's planes at scale 1 — where the range guard leaves a hot
+    checkpoint — with the fp32 parity gate green on it)."""
+    env = dict(os.environ, PRAM_BENCH_ALTS="sustained,act_scale_1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--batch-per-gpu", "2", "--cpu-queries", "0",
+                        "--alt", "on"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    alt = d["alt"]
+    assert set(alt) == {"sustained", "act_scale_1"} and not any("error" in v for v in alt.values()), alt
+    su = alt["sustained"]
+    assert su["seconds"] >= 9.0 and su["distinct_batches"] == 4 and 0.8 < su["ratio_to_value"] < 2.0      # (a 4-step headline of 2 queries is not warm: the default run reads 0.999)
+    assert su["power"] is None or len(su["power"]["trace"]) == 10
+    a1 = alt["act_scale_1"]
+    assert a1["parity"]["ok"] and a1["parity"]["match_indices_identical"] and a1["parity"]["logits_maxdiff_max"] < 1e-3
+    assert d["alt_parity_failed"] == []
+
+
 def test_bench_latency_mode_line(hip_lib):
     """`--latency`: one query per step, nothing in flight, the step replayed from captured graphs on two streams, 512-key attention
     chunks (split launches); the parity gate runs on the same arithmetic."""
@@ -109,6 +128,9 @@ def test_bench_eight_ranks_on_one_device(hip_lib, total):
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["queries_per_step"] == total
     assert d["config"]["queries_per_gpu_per_step"] == want and d["config"]["gather_order_verified"] is True
     assert len(d["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    # what explains a curve: per-rank host issue time, the all-gather's time on the main stream (the wait for the slowest rank inside), the skew
+    assert len(d["per_rank_host_issue_ms_per_step"]) == 8 and len(d["per_rank_gather_ms"]) == 8 and all(g >= 0 for g in d["per_rank_gather_ms"])
+    assert abs(d["rank_skew_ms_per_step"] - (max(d["per_rank_ms_per_step"]) - min(d["per_rank_ms_per_step"]))) < 2e-3
     assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) < 1e-3 * d["ms_per_step"] + 1e-3
     assert abs(d["value"] - total * 2 / (d["ms_per_step"] * 2e-3)) < 0.05 * d["value"]
 
