@@ -379,3 +379,37 @@ def test_product_path_rejects_cpu(dev):
     desc, kp = _tokens(1, 64)
     with pytest.raises(PramHipError):
         _segnet(dev)({"seg_descriptors": desc, "keypoints": kp, "image": torch.empty(1, 3, 480, 640)})
+
+
+@pytest.mark.parametrize("scale", [1.0, 1.0 / 16.0])
+def test_models_keep_parity_at_lower_activation_scales(dev, golden, scale):
+    """The three model families with their activation planes at scale 1 / 2^-4 instead of 16 (where the range guard leaves a
+    checkpoint with hot activations): the same golden vectors, the same bars — fp32 outputs 1e-3, match indices exact, SFD2's
+    dense maps 1e-4 — on in-range data whose small values now sit far below the planes' scale."""
+    # SegNetViT
+    g = golden("segnetvit_b2_n512_c113")
+    desc, kp = _tokens(2, 512)
+    net = _segnet(dev, 113).set_act_scale(scale)
+    out = net({"seg_descriptors": desc.to(dev), "keypoints": kp.to(dev), "image": torch.empty(2, 3, 480, 640)})["prediction"]
+    d = np.abs(H.subsample(out.cpu(), 8192).numpy() - g["logits_sub"]).max()
+    agree = (out.argmax(-1).cpu().numpy().astype(np.int16) == g["argmax"]).mean()
+    assert net.act_scale == scale and d < 1e-3 and agree > 0.999, (d, agree)
+    # GML
+    g = golden("gml_m384_n512")
+    data, _ = H.pair_data(0, 384, 512, "image_shape", device=dev)
+    gm = _gml(dev).set_act_scale(scale)
+    r, r0 = gm(data), gm.produce_matches(data, p=0.0)
+    ds = np.abs(r0["matching_scores0"].cpu().numpy() - g["s0"]).max()
+    assert ds < 1e-3, ds
+    for got, want in ((r["matches0"], g["m0_def"]), (r["matches1"], g["m1_def"]), (r0["matches0"], g["m0_p0"])):
+        assert np.array_equal(got.cpu().numpy(), want)
+    # SFD2 (convolution planes, the fused conv1, the grouped 3 x 3 on planes)
+    sf = _sfd2(dev).set_act_scale(scale)
+    img = torch.stack([W.synthetic_image(1, 96, 128), W.synthetic_image(2, 96, 128)])
+    o = R.sfd2_extract_local_global(H.sfd2_sd(), img, max_keypoints=64, min_keypoints=8)
+    rr = sf.extract_local_global({"image": img.to(dev)}, {"max_keypoints": 64, "min_keypoints": 8})
+    dm = {k: H.maxdiff(rr[k], o[k]) for k in ("score_map", "desc_map", "mid_features")}
+    print(f"activation scale {scale:g}: segnet |logit - golden| {d:.2e}, gml |score - golden| {ds:.2e}, sfd2 dense maps {dm}")
+    assert all(v < 1e-4 for v in dm.values()), dm
+    from pram_amd import ops
+    assert ops.current_act_scale() == 16.0 and not ops.x3_range_exceeded(dev)
