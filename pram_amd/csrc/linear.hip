@@ -73,6 +73,19 @@ struct LnGeluXf {
     const float* gb; int K; int kq;      // kq = this thread's float4 column inside a BKC-deep chunk
     float rstd[PA];
     __device__ __forceinline__ void operator()(float4& v, int p, int kt) const {
+#if defined(PRAM_LNA_ABLATE) && (PRAM_LNA_ABLATE == 1 || PRAM_LNA_ABLATE == 4)      // profiling: no transform at all (prologue kept)
+        (void)p; (void)kt;
+#elif defined(PRAM_LNA_ABLATE) && PRAM_LNA_ABLATE == 2     // profiling: LayerNorm's affine only
+        const int k = kt * BKC + kq * 4;
+        const float4 g = *reinterpret_cast<const float4*>(gb + k);
+        const float4 b = *reinterpret_cast<const float4*>(gb + K + k);
+        const float rs = rstd[p];
+        v.x = v.x * rs * g.x + b.x; v.y = v.y * rs * g.y + b.y; v.z = v.z * rs * g.z + b.z; v.w = v.w * rs * g.w + b.w;
+#elif defined(PRAM_LNA_ABLATE) && PRAM_LNA_ABLATE == 3     // profiling: GELU only (no gamma | beta reads)
+        const float rs = rstd[p];
+        (void)kt;
+        v.x = gelu_erf(v.x * rs); v.y = gelu_erf(v.y * rs); v.z = gelu_erf(v.z * rs); v.w = gelu_erf(v.w * rs);
+#else
         const int k = kt * BKC + kq * 4;
         const float4 g = *reinterpret_cast<const float4*>(gb + k);
         const float4 b = *reinterpret_cast<const float4*>(gb + K + k);
@@ -81,6 +94,7 @@ struct LnGeluXf {
         v.y = gelu_erf(v.y * rs * g.y + b.y);
         v.z = gelu_erf(v.z * rs * g.z + b.z);
         v.w = gelu_erf(v.w * rs * g.w + b.w);
+#endif
     }
 };
 
@@ -745,6 +759,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
         float amax = 0.f;
         if constexpr (LNA) {
             // prologue loads all in flight together, as in linear_x3_kernel (K <= 1024, 512 threads: two rounds of gamma | beta)
+#if defined(PRAM_LNA_ABLATE) && PRAM_LNA_ABLATE == 4      // profiling: no prologue, no transform
+            LnGeluXf<C::PA> xf0;
+            xf0.gb = lngb; xf0.K = K; xf0.kq = akq;
+            for (int pp = 0; pp < C::PA; ++pp) xf0.rstd[pp] = 1.0f;
+            mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, p.act_scale, acc, amax, xf0);
+#else
             {
                 float gv[2], bv[2];
 #pragma unroll
@@ -762,6 +782,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void linear_x3w_kernel(LinArgs p, 
             }
             __syncthreads();
             mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, K / BK, p.act_scale, acc, amax, xf);
+#endif
         } else {
             mainloop<MI, WM, WN, false, ABL, (DMA ? 1 : 0)>(smem, adv, la, oka, lb, okb, aptr, bptr, ABL == 128 ? 1 : (ABL == 256 && (blockIdx.x & 1) && blockIdx.x < 256) ? K / BK / 2 : K / BK, p.act_scale, acc, amax);
         }
