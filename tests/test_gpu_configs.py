@@ -165,3 +165,21 @@ def test_c3_pipeline_b16_full_size(dev):
         solo = pipe.run(images[b:b + 1], {k: v[b:b + 1] for k, v in ref.items()})
         for key in ("keypoints", "scores", "descriptors", "prediction", "matches0", "matching_scores0", "landmark"):
             assert torch.equal(out[key][b], solo[key][0]), (b, key)
+
+
+def test_c5_fp16_pipeline_discrete_outputs_as_fractions(dev):
+    """C5 end to end on the fp16 MFMA path (one 640 x 480 frame, 4096 keypoints, nc513, GML against a 4096-keypoint reference set)
+    through bench.parity_gate(f16=True): the recogniser inside its documented bars, and the path's DISCRETE outputs — which keypoints,
+    which match indices — gated as agreement FRACTIONS with the fp32 oracle (bench.F16_BARS: 1.5 x the measured deficit), not as
+    booleans that cannot say whether one or a thousand differ."""
+    import bench
+    from pram_amd import ops
+    job = bench.Job(dev, 0, 1, 0, 1, "gml", 4096, 513, "erm", 1, False, precision="f16")
+    with torch.no_grad(), ops.precision_scope("f16"):
+        pq = bench.parity_gate(job.pipe, job.sds, "gml", job.images, job.ref, 4096, queries=(0,), f16=True)
+    print({k: v for k, v in pq.items() if k != "per_query"})
+    assert pq["ok"], pq
+    assert pq["keypoint_set_overlap_min"] >= bench.F16_BARS["kp_overlap"] and pq["match_index_agreement_min"] >= bench.F16_BARS["match_agree"]
+    assert pq["logits_maxdiff_max"] < bench.F16_BARS["logits"] and pq["argmax_agreement_min"] >= bench.F16_BARS["argmax"]
+    if ops.x3_launched(dev):
+        assert not ops.x3_range_exceeded(dev)
