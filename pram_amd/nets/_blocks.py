@@ -230,6 +230,16 @@ class PackedCache:
         self.act_scale = s
         return self
 
+    def calibrate_act_scale(self, run):
+        """Settle the activation scale on representative inputs BEFORE serving (or capturing a hipGraph): `run` is a callable that
+        pushes a calibration sample through this model's guarded entry point (``lambda: model(data)``, ``lambda:
+        matcher.produce_matches(pair)``).  Starts from the default 16, lets the range guard lower it as far as the sample needs
+        (policy "fallback") and returns the scale the model keeps.  A sample inside the default range costs one forward."""
+        self.act_scale = ops.ACT_SCALE_DEFAULT
+        with ops.guard_scope("fallback"):
+            run()
+        return self.act_scale
+
     def set_precision(self, p: Optional[str]):
         self.precision = None if p is None else ops._check_precision(p)
         return self

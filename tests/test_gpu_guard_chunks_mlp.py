@@ -119,6 +119,15 @@ def test_range_guard_lowers_the_activation_scale_on_a_hot_residual_stream(dev, m
         again = net.set_precision("x3")(data)["prediction"]
     assert torch.equal(again, got) and ops.guard_events == ev1                   # sticky: no trip, no re-run, same bits
     net.set_precision(None)
+    # the same thing up front: calibrate on a sample before serving / capturing
+    net_c, _ = _hot_segnet(dev, 6.0e3)
+    assert net_c.set_precision("x3").calibrate_act_scale(lambda: net_c(data)) == 1.0 and net_c.act_scale == 1.0
+    ev2 = dict(ops.guard_events)
+    with ops.guard_scope("raise"):
+        assert torch.equal(net_c(data)["prediction"], got)                       # in range now: nothing to raise about, the same bits
+    assert ops.guard_events == ev2
+    cool, _ = _hot_segnet(dev, 1.0)
+    assert cool.calibrate_act_scale(lambda: cool(data)) == 16.0
     # a stream the allowed scales cannot carry ends on the exact-fp32 kernels, as before (here: scales limited to >= 1, |x| ~ 7e4, attention logits ~ 1e9)
     monkeypatch.setattr(ops, "ACT_SCALE_MIN", 1.0)
     net3, _ = _hot_segnet(dev, 6.0e4)
