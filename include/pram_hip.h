@@ -48,7 +48,8 @@ int pram_hip_version(void);
 const char* pram_last_error(void);
 
 /* ---------------------------------------------------------------- range guard of the split-fp16 ("x3") entries
- * The x3 entries carry every fp32 activation as two fp16 parts of value * 16.  A finite value with |16 x| >= 65520 rounds to
+ * The x3 entries carry every fp32 activation as two fp16 parts of value * s (s = the activation scale below, 16 by default).  A finite
+ * value with |s x| >= 65520 rounds to
  * +-inf in its hi part and the result of the launch is garbage (usually NaN — but NaN scores turn into ordinary-looking
  * indices further down).  Kernel launches are asynchronous, so this cannot come back as a return code of the launch: every x3
  * kernel that splits fp32 values (GEMM / convolution operand staging, the plane-writing epilogues) ORs PRAM_STATUS_X3_RANGE
@@ -147,7 +148,7 @@ int pram_linear_x3_qkv_f32(const float* a0, int lda0, int k0, const void* w_hi, 
                            int heads, int t_seq, int m, int n, int flags, const float* rot_cos, const float* rot_sin,
                            int rot_cols, const int* lens, void* stream);
 
-/* pram_linear_x3_f32 with the activations already split: [A0 | A1] given as fp16 planes (value * 16 = hi + lo, [m][lda]
+/* pram_linear_x3_f32 with the activations already split: [A0 | A1] given as fp16 planes (value * s = hi + lo, s = pram_x3_set_act_scale's value in force at the PRODUCER's launch and here, 16 by default; [m][lda]
  * halves) written by the epilogues of pram_linear_x3[p]_f32 / pram_attention_x3_f32 / pram_layernorm_gelu_x3.  Both operands are
  * then staged with plain 16-byte copies (the fp32-input form splits A again in every column tile and is instruction-issue
  * bound).  k0, k1 multiples of 32; lda multiples of 8. */
@@ -177,7 +178,7 @@ int pram_bgemm_nt_f32(const float* a, int lda, long long stride_a, const float* 
                       long long stride_b, float* c, int ldc, long long stride_c, int batch,
                       int m_max, int n_max, int k, float alpha, void* stream);
 
-/* pram_bgemm_nt_f32 on the split-fp16 path: both operands as split planes (value * 16 = hi + lo, what the projection epilogues
+/* pram_bgemm_nt_f32 on the split-fp16 path: both operands as split planes (value * s = hi + lo at the activation scale in force, what the projection epilogues
  * write: pram_linear_x3_f32 out_hi / out_lo): a [m_max][lda], b [n_max][ldb == k] per batch element; strides in halves for the
  * planes, in floats for c.  k % 32 == 0, lda and the plane strides % 8 == 0.  Three fp16 MFMAs per product, fp32-class result. */
 int pram_bgemm_nt_x3p_f32(const void* a_hi, const void* a_lo, int lda, long long stride_a, const void* b_hi, const void* b_lo,
@@ -233,7 +234,7 @@ int pram_attention_h16_f32(const void* q16, int ldq, const void* k16, int ldk, c
                            int m_max, int n_max, float scale, int kv_shift, void* stream);
 
 /* Split-fp16 ("x3") flash attention — the default attention of the fp32 parity path (same einsum -> softmax -> einsum
- * sites as pram_attention_f32).  q / k are row-major split planes written by pram_linear_x3_f32 (value * 16 = hi + lo,
+ * sites as pram_attention_f32).  q / k are row-major split planes written by pram_linear_x3_f32 (value * s = hi + lo at the activation scale in force,
  * ld* in halves, multiples of 8; heads are 64-wide column blocks); vt_hi / vt_lo are the TRANSPOSED value planes of the
  * key side built by pram_attention_x3_vt: [batch][heads][64][tv], tv = n_max rounded up to 64.  S = K Q^T and O = P V are
  * fp16 MFMAs with fp32 accumulation: three per product for the scores and, by default, three per product for P V (the
@@ -397,7 +398,7 @@ int pram_conv2d_nhwc_x3_l2norm_f32(const float* in, int batch, int h, int w, int
                                    float* out, int cout, int ks, int stride, int relu, void* stream);
 
 /* pram_conv2d_nhwc_x3_f32 whose result leaves as the split operand of the next split-fp16 layer instead of fp32: out_hi =
- * fp16(16 y), out_lo = fp16(16 y - out_hi), [batch][ho][wo][cout] each — the same four bytes per value, and the consumer needs
+ * fp16(s y), out_lo = fp16(s y - out_hi) (s = the activation scale in force, 16 by default), [batch][ho][wo][cout] each — the same four bytes per value, and the consumer needs
  * neither registers nor vector instructions to stage it (LDS-DMA).  cin % 32 == 0, cout even; |y| >= 4095 is reported through the
  * range guard (status word).  Used between a ResBlock's first 1x1 and its grouped 3x3. */
 int pram_conv2d_nhwc_x3_planes(const float* in, int batch, int h, int w, int cin, const void* wgt_hi, const void* wgt_lo,

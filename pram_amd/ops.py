@@ -251,8 +251,8 @@ def linear_qkv_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
 def linear_planes(x, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x2=None, residual: Optional[torch.Tensor] = None,
                   alpha: float = 1.0, rotary: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, out: str = "f32"):
     """linear() on the split-fp16 path with the activations ALREADY split: x (and x2) are (hi, lo) pairs of fp16 2-D views
-    (value * 16 = hi + lo) written by a producing kernel's epilogue.  out: "f32" -> fp32 tensor; "planes" -> (hi, lo) planes of
-    the result * 16; "both" -> (fp32, (hi, lo))."""
+    (value * s = hi + lo, s = the activation scale in force: 16 unless a model / act_scale_scope lowered it) written by a producing kernel's epilogue.  out: "f32" -> fp32 tensor; "planes" -> (hi, lo) planes of
+    the result * s; "both" -> (fp32, (hi, lo))."""
     L = _lib.load()
     xh, xl = x
     assert xh.dtype == torch.float16 and xh.dim() == 2 and xh.stride(1) == 1 and xh.stride(0) == xl.stride(0)
