@@ -124,3 +124,59 @@ def test_new_entry_points_are_declared_bound_and_exported():
         assert L.pram_attention_x3_is_split(16, 4, 2048, 2048) == 1 and L.pram_attention_x3_is_split(1, 4, 512, 512) == 1
     finally:
         L.pram_attention_x3_set_chunk_keys(4096)
+
+
+def test_guard_lowers_scales_before_it_leaves_the_split_path(monkeypatch):
+    """ops.guarded_call's policy on a host without a GPU (the device reads are stubbed): a tripped guard divides the activation scale of
+    every model that ran inside the call by 16 and re-runs; the models keep it; only when no scale is left (ACT_SCALE_MIN) does the
+    call run under forced_precision('f32'); 'raise' raises; 'deferred' and an un-armed device return at once; nested guarded calls
+    leave the decision to the outermost one."""
+    from pram_amd import ops
+    from pram_amd._lib import PramHipError
+
+    class Model:
+        act_scale = 16.0
+
+    trips = {"left": 0}
+    runs = []
+    monkeypatch.setattr(ops, "x3_launched", lambda device=None: True)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+
+    def exceeded(device=None, reset=True):
+        if trips["left"] > 0:
+            trips["left"] -= 1
+            return True
+        return False
+    monkeypatch.setattr(ops, "x3_range_exceeded", exceeded)
+    a, b = Model(), Model()
+
+    def call():
+        for m in (a, b):
+            ops.guarded_call(lambda m=m: ops.note_model_ran(m), "dev")      # nested model calls: registered, never deciding
+        runs.append((a.act_scale, b.act_scale, ops.gemm_prec()))
+        return len(runs)
+
+    ev = dict(ops.guard_events)
+    with ops.guard_scope("fallback"):
+        trips["left"] = 2                                                   # trips at 16 and at 1, fits at 1/16
+        assert ops.guarded_call(call, "dev") == 3
+    assert [r[:2] for r in runs] == [(16.0, 16.0), (1.0, 1.0), (1.0 / 16, 1.0 / 16)] and a.act_scale == 1.0 / 16
+    assert ops.guard_events["rescaled"] == ev["rescaled"] + 2 and ops.guard_events["f32_fallback"] == ev["f32_fallback"]
+    runs.clear()
+    with ops.guard_scope("fallback"):
+        trips["left"] = 5                                                   # nothing fits: 1/16 -> 1/256 -> the exact-fp32 kernels
+        ops.guarded_call(call, "dev")
+    assert [r[0] for r in runs] == [1.0 / 16, 1.0 / 256, 1.0 / 256] and runs[-1][2] == "f32" and runs[0][2] != "f32"
+    assert ops.guard_events["f32_fallback"] == ev["f32_fallback"] + 1 and a.act_scale == 1.0 / 256
+    trips["left"] = 1
+    with ops.guard_scope("raise"):
+        try:
+            ops.guarded_call(call, "dev")
+            raise AssertionError("the raise policy must raise")
+        except PramHipError:
+            pass
+    trips["left"] = 1
+    n = len(runs)
+    with ops.guard_scope("deferred"):
+        ops.guarded_call(call, "dev")
+    assert len(runs) == n + 1 and trips["left"] == 1                        # never asked
